@@ -1,0 +1,220 @@
+"""Headline benchmark: 512x512 images/sec, SD-v1-4 architecture, 50-step PLMS, CFG 7.5 (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 3 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one image per GPU: `PLMSSamplerHIP.sample` (51 UNet calls through libsdmi's gfx950 kernels, fused
+CFG + PLMS update) followed by the VAE decode on stock PyTorch-ROCm (north_star keeps the VAE there).  Weights are
+seeded random tensors in the exact SD-v1 architecture and the conditioning is synthetic (there is no checkpoint /
+CLIP vocabulary in the environment); throughput is value independent.  N > 1: one process per GPU, one prompt per
+GPU (weak scaling), no data-path collective; the finished latents are all-gathered once per step (RCCL).
+
+Rank 0 prints ONE JSON line.  At N = 1 it also carries
+  "roofline":     achieved TFLOP/s of the dominant kernel class, timed live with HIP events on the launch stream
+                  (sdmi_profile_begin/end) over one UNet call of the same workload, vs the dense fp16 MFMA peak;
+  "cpu_baseline": the oracle (CPU restatement of the reference, fp32, all host cores) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0
+UNET_GFLOP_64 = 1606.5        # one UNet call, CFG batch 2, latent 64x64
+
+
+def build_gpu_model(device, seed=0):
+    from stable_diffusion_amd import LatentDiffusionHIP, UNetModelHIP
+    from stable_diffusion_amd.synthetic import SD_V1_UNET_KWARGS, randomize_
+    from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
+    unet = UNetModelHIP(**SD_V1_UNET_KWARGS)
+    ld = LatentDiffusionHIP(unet).to(device).eval()
+    randomize_(unet, seed)
+    torch.manual_seed(seed)
+    vae = AutoencoderKLDecoder().to(device).eval()
+    return ld, unet, vae
+
+
+def one_image(sampler, vae, c, uc, x_T, steps_plms=50, scale=7.5):
+    lat, _ = sampler.sample(S=steps_plms, batch_size=1, shape=list(x_T.shape[1:]), conditioning=c, verbose=False,
+                            x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=uc, eta=0.0)
+    with torch.autocast('cuda', dtype=torch.float16):
+        img = vae.decode_first_stage(lat)
+    img = torch.clamp((img.float() + 1.0) / 2.0, min=0.0, max=1.0)     # scripts/txt2img.py:314
+    return lat, img
+
+
+def profile_unet(unet, device, H=64, W=64):
+    """One UNet call (CFG batch 2) with per-launch HIP-event timing; returns the per-kernel-class table."""
+    from stable_diffusion_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator(device='cpu').manual_seed(3)
+    x = torch.randn(2, 4, H, W, generator=g).to(device)
+    ctx = (0.1 * torch.randn(2, 77, 768, generator=g)).to(device)
+    t = torch.tensor([481, 481], device=device)
+    unet(x, t, context=ctx)
+    torch.cuda.synchronize()
+    _lib.check(lib.sdmi_profile_begin())
+    unet(x, t, context=ctx)
+    buf = bytes(1 << 16)
+    import ctypes
+    cbuf = ctypes.create_string_buffer(1 << 16)
+    _lib.check(lib.sdmi_profile_end(cbuf, 1 << 16))
+    return json.loads(cbuf.value.decode())
+
+
+def unet_latency_ms(unet, device, H=64, W=64, iters=10):
+    g = torch.Generator(device='cpu').manual_seed(4)
+    x = torch.randn(2, 4, H, W, generator=g).to(device)
+    ctx = (0.1 * torch.randn(2, 77, 768, generator=g)).to(device)
+    t = torch.tensor([481, 481], device=device)
+    unet.pin_context(ctx)
+    for _ in range(2):
+        unet(x, t, context=ctx)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        unet(x, t, context=ctx)
+    torch.cuda.synchronize()
+    unet.unpin_context()
+    return (time.perf_counter() - t0) / iters * 1e3
+
+
+def cpu_baseline(n_unet_calls=2):
+    """The oracle (fp32 CPU restatement of the reference UNet) + the VAE decoder on the host cores; bounded sample:
+    `n_unet_calls` UNet calls at the full workload shape (CFG batch 2, latent 64x64) and one VAE decode, extrapolated
+    to 51 calls + 1 decode per image."""
+    from oracle import unet_ref
+    from oracle.plan import SD_V1
+    from oracle.weights import make_inputs, make_state_dict
+    from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
+    cores = os.cpu_count()
+    torch.set_num_threads(cores)
+    sd = make_state_dict(SD_V1, 0)
+    x, t, ctx = make_inputs(SD_V1, 2, 64, 64, seed=1)
+    times = []
+    for _ in range(n_unet_calls):
+        t0 = time.perf_counter()
+        unet_ref.unet_forward(sd, SD_V1, x, t, ctx)
+        times.append(time.perf_counter() - t0)
+    t_unet = min(times)
+    torch.manual_seed(0)
+    vae = AutoencoderKLDecoder().eval()
+    z = torch.randn(1, 4, 64, 64)
+    t0 = time.perf_counter()
+    vae.decode_first_stage(z)
+    t_vae = time.perf_counter() - t0
+    s_per_image = 51 * t_unet + t_vae
+    return {'value': 1.0 / s_per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
+            'sample': f'{n_unet_calls} oracle UNet calls (fp32, B=2, 64x64 latent: {t_unet:.2f} s each) + 1 VAE decode '
+                      f'({t_vae:.2f} s), extrapolated to 51 calls + 1 decode = {s_per_image:.1f} s/image'}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-roofline', action='store_true')
+    args = ap.parse_args()
+
+    from stable_diffusion_amd import PLMSSamplerHIP
+    from stable_diffusion_amd import dist as sd_dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    rank, world, local_rank = sd_dist.init_from_env()
+    assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}'
+    device = torch.device('cuda', local_rank if world > 1 else 0)
+    torch.cuda.set_device(device)
+
+    ld, unet, vae = build_gpu_model(device)
+    sampler = PLMSSamplerHIP(ld)
+    # synthetic conditioning / start codes; the seed depends on the GLOBAL prompt index only
+    def inputs(step):
+        gidx = step * world + rank
+        g = torch.Generator(device='cpu').manual_seed(1000 + gidx)
+        c = (0.1 * torch.randn(1, 77, 768, generator=g)).to(device)
+        x_T = torch.randn(1, 4, 64, 64, generator=g).to(device)
+        return c, x_T
+    guc = torch.Generator(device='cpu').manual_seed(2)
+    uc = (0.1 * torch.randn(1, 77, 768, generator=guc)).to(device)
+
+    import io
+    import contextlib
+    quiet = contextlib.redirect_stdout(io.StringIO())
+    with quiet:
+        for w in range(args.warmup):
+            c, x_T = inputs(-1 - w)
+            one_image(sampler, vae, c, uc, x_T)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    with quiet:
+        for s in range(args.steps):
+            c, x_T = inputs(s)
+            lat, img = one_image(sampler, vae, c, uc, x_T)
+            allz = sd_dist.gather_latents(lat, world, rank, world)     # the only collective: 64 KiB per image
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    elapsed = sd_dist.max_over_ranks(time.perf_counter() - t0, device)
+    assert torch.isfinite(img).all() and torch.isfinite(allz).all()
+
+    out = None
+    if rank == 0:
+        n_images = args.steps * world
+        out = {
+            'metric': '512x512 images/sec, SD-v1-4 50-step PLMS CFG=7.5',
+            'value': n_images / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': 'SD-v1-4 UNet (859.5M params, random init), latent 4x64x64 (512x512), 50 PLMS steps = '
+                                   '51 UNet calls at CFG batch 2, scale 7.5, 1 prompt per GPU per step, + VAE decode '
+                                   '(PyTorch-ROCm fp16 autocast)',
+                       'global_batch': world, 'parallelism': f'dp{world} (one prompt per GPU, latents all_gather)'},
+        }
+        if world == 1:
+            ms = unet_latency_ms(unet, device)
+            out['unet_ms_per_call'] = ms
+            out['unet_tflops'] = UNET_GFLOP_64 / ms
+            if not args.no_roofline:
+                table = profile_unet(unet, device)
+                table.sort(key=lambda r: -r['ms'])
+                dom = table[0]
+                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'attn'))]
+                ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['flops'] > 0 else None
+                out['roofline'] = {
+                    'bound': 'mfma', 'kernel': dom['name'], 'launches_per_unet_call': dom['launches'],
+                    'avg_launch_ms': dom['ms'] / dom['launches'],
+                    'achieved': ach, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+                    'frac': (ach / MFMA_PEAK_TFLOPS) if ach else None, 'traffic': None,
+                    'algorithmic_gbytes_per_launch': dom['bytes'] / dom['launches'] / 1e9,
+                    'per_class': [{'name': r['name'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
+                                   'tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if r['flops'] else None,
+                                   'gbs': round(r['bytes'] / (r['ms'] * 1e-3) / 1e9, 1)} for r in table],
+                    'mfma_classes_tflops': sum(r['flops'] for r in mfma) / (sum(r['ms'] for r in mfma) * 1e-3) / 1e12
+                    if mfma else None,
+                }
+            if not args.no_cpu_baseline:
+                out['cpu_baseline'] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

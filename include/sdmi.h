@@ -1,0 +1,138 @@
+/* libsdmi -- MI355X (gfx950) native UNet eps-prediction + PLMS/DDIM step for Stable Diffusion v1.
+ *
+ * C ABI of the drop-in boundary.  The reference (CompVis/stable-diffusion) is pure Python and has no FFI
+ * of its own; each entry point below names the reference call it stands in for (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding and the yaml `target:` switch that plugs it in.
+ *
+ * Conventions
+ *   - every function returns 0 on success, <0 on error; sdmi_last_error() gives the thread-local message.
+ *   - all pointers are DEVICE pointers on the current HIP device unless stated otherwise;
+ *     activations cross the boundary as contiguous fp32 in the reference's own layouts (NCHW latents,
+ *     [B,L,D] context, int64 timesteps).
+ *   - `stream` is a hipStream_t (pass torch.cuda.current_stream().cuda_stream); the library only enqueues
+ *     work on it and never synchronises the device.
+ *   - the library owns packed weights; the caller owns inputs, outputs and the workspace.
+ */
+#ifndef SDMI_H_
+#define SDMI_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SDMI_ABI_VERSION 1
+
+typedef struct sdmi_unet sdmi_unet;
+
+/* Constructor arguments of UNetModel used by configs/stable-diffusion/v1-inference.yaml:29-44
+ * (ldm/modules/diffusionmodules/openaimodel.py:443-470).  use_spatial_transformer=True, legacy=False. */
+typedef struct sdmi_unet_cfg {
+  int32_t in_channels;
+  int32_t out_channels;
+  int32_t model_channels;
+  int32_t num_res_blocks;
+  int32_t n_levels;
+  int32_t channel_mult[8];
+  int32_t n_attention_resolutions;
+  int32_t attention_resolutions[8];
+  int32_t num_heads;
+  int32_t transformer_depth;
+  int32_t context_dim;
+} sdmi_unet_cfg;
+
+const char* sdmi_last_error(void);
+int sdmi_abi_version(void);
+
+/* ---- UNet handle: replaces instantiate_from_config(unet_config) + load_state_dict ----------------------- */
+/* UNetModel.__init__, openaimodel.py:443-692 */
+int sdmi_unet_create(const sdmi_unet_cfg* cfg, sdmi_unet** out);
+int sdmi_unet_destroy(sdmi_unet* h);
+/* enumerate the state_dict keys the handle expects (= UNetModel.state_dict().keys()) */
+int sdmi_unet_num_weights(const sdmi_unet* h);
+int sdmi_unet_weight_info(const sdmi_unet* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim);
+/* model.load_state_dict (scripts/txt2img.py:56): fp32 tensor in the reference layout (conv OIHW, linear [out,in]);
+ * `ptr` may be a device or a host pointer.  The library repacks (fp16 [N][K], K=(ky,kx,cin)) and keeps its own copy. */
+int sdmi_unet_set_weight(sdmi_unet* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream);
+/* fails (listing the first missing key) unless every expected tensor was set */
+int sdmi_unet_finalize(sdmi_unet* h);
+
+/* bytes of scratch `sdmi_unet_forward` needs for this shape (0 on error) */
+int64_t sdmi_unet_workspace_bytes(sdmi_unet* h, int B, int H, int W, int Lctx);
+
+/* Cross-attention K/V of all SpatialTransformers depend only on the context (attention.py:174-176):
+ * compute them once per prompt.  ctx: fp32 [B, Lctx, context_dim]. */
+int sdmi_unet_cache_context(sdmi_unet* h, const float* ctx, int B, int Lctx, void* workspace, int64_t workspace_bytes,
+                            void* stream);
+
+/* UNetModel.forward(x, timesteps, context) openaimodel.py:710-742, reached through
+ * LatentDiffusion.apply_model ddpm.py:891-900,986-992 and DiffusionWrapper.forward ddpm.py:1402-1410.
+ *   x        fp32 [B, in_channels, H, W] (NCHW, contiguous)
+ *   t_i64 / t_f32   exactly one non-NULL: [B] timesteps (int64 as the samplers pass; fp32 for DPM-Solver)
+ *   ctx      fp32 [B, Lctx, context_dim], or NULL to reuse sdmi_unet_cache_context()'s result
+ *   eps_out  fp32 [B, out_channels, H, W] -- written fresh on every call */
+int sdmi_unet_forward(sdmi_unet* h, const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx,
+                      float* eps_out, int B, int H, int W, int Lctx, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
+/* ---- sampler step: classifier-free guidance combine + PLMS / DDIM update in one launch -------------------
+ * PLMSSampler.p_sample_plms plms.py:172-236, DDIMSampler.p_sample_ddim ddim.py:165-204.
+ *   eps_model: model output; cfg != 0 -> rows [0,n) are the unconditional half, [n,2n) the conditional half
+ *   mode: 0 e'=e_t | 1 (3e-o0)/2 | 2 (23e-16o0+5o1)/12 | 3 (55e-59o0+37o1-9o2)/24 | 4 (o0+e_t)/2
+ *   a_t, a_prev, sigma, sqrt_1m_at: the four table entries the reference indexes per step
+ *   noise (optional, sigma>0), e_t_out (optional: post-CFG eps for the history), pred_x0 (optional) */
+int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float* x, int mode, const float* old0,
+                      const float* old1, const float* old2, float a_t, float a_prev, float sigma, float sqrt_1m_at,
+                      const float* noise, float* e_t_out, float* x_prev, float* pred_x0, int64_t n, void* stream);
+
+/* ---- kernel-level entry points (parity tests and micro-benchmarks; same kernels the UNet uses) ---------- */
+typedef struct sdmi_igemm_desc {
+  const void* a0; const void* a1;       /* fp16 NHWC sources (a1 optional: channel concat) */
+  int32_t c0, c1, lda0, lda1;
+  int32_t B, Hin, Win, Hout, Wout, ksize, stride, up;
+  const void* w;                        /* fp16 [N][K], K = ksize*ksize*(c0+c1) ordered (ky,kx,cin) */
+  int32_t N;
+  int32_t mode;                         /* 0 plain, 1 GEGLU (w/bias packed by sdmi_k_pack_geglu), 2 per-head scatter */
+  const float* bias; const float* rowvec; int32_t ld_rowvec;
+  const float* residual; int32_t ldr;
+  float* out_f32; void* out_f16; int32_t ldo;
+  void* seg_dst[3]; int32_t seg_kind[3];
+  int32_t heads, dh, ntok, ntok_pad, segC;
+  int32_t splitk;                       /* 1 none, 0 auto, >1 forced */
+  int32_t tile;                         /* -1 auto, 0 128x128, 1 128x64, 2 64x64 */
+  int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
+} sdmi_igemm_desc;
+int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
+/* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
+int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
+                     int nkv_pad, int d, float scale, void* stream);
+/* GroupNorm(32) over cat(x0,x1) fp32 NHWC; any of out_f16 / out_f32 / raw_f16 may be NULL */
+int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
+                     const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16,
+                     float* partial_ws, int64_t partial_floats, void* stream);
+int64_t sdmi_k_groupnorm_ws_floats(int B, int HW);
+int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
+                     void* stream);
+int sdmi_k_cast_f16(const float* x, void* out_f16, int64_t n, void* stream);
+int sdmi_k_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, void* stream);
+int sdmi_k_small_linear(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out, int B,
+                        int N, int K, int silu_in, void* stream);
+int sdmi_k_conv_in(const float* x_nchw, const float* w_oihw, const float* bias, float* out_nhwc, int B, int Cin, int H,
+                   int W, int Cout, void* stream);
+int sdmi_k_conv_out(const float* h_nhwc, const float* w_ohwi, const float* bias, float* out_nchw, int B, int H, int W,
+                    int Cin, int Cout, void* stream);
+int sdmi_k_pack_conv_weight(const float* w_oihw, void* dst_f16, int O, int I, int KH, int KW, void* stream);
+int sdmi_k_pack_conv_out(const float* w_oihw, float* dst_ohwi, int O, int I, void* stream);
+int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst_f16, float* bdst, int N, int K, void* stream);
+/* per-launch timing of the library's kernels (HIP events on the launch stream): begin, run forwards, then end
+ * writes a JSON array [{"name","launches","ms","flops","bytes"}] (algorithmic flops / bytes per kernel class) */
+int sdmi_profile_begin(void);
+int sdmi_profile_end(char* json_buf, int json_buf_len);
+/* a device buffer of >= 256 zero bytes owned by the library (out-of-image conv taps read it) */
+const void* sdmi_zero_page(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SDMI_H_ */

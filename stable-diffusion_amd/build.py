@@ -1,0 +1,75 @@
+"""Build libsdmi.so (hipcc, gfx950) in-tree.  `python stable-diffusion_amd/build.py [--force]`.
+
+hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
+`stable-diffusion_amd/libsdmi.so` travels to the GPU box with the repo snapshot.
+"""
+import concurrent.futures as cf
+import hashlib
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIB = os.path.join(HERE, 'libsdmi.so')
+SOURCES = ['igemm.hip', 'attn.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'api.cpp', 'prof.cpp']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
+         '-Wno-unused-variable']
+
+
+def _hipcc():
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (not os.path.isabs(c) or os.path.exists(c)):
+            return c
+    raise RuntimeError('hipcc not found')
+
+
+def _stamp():
+    h = hashlib.sha256()
+    for root in (CSRC, os.path.join(os.path.dirname(HERE), 'include')):
+        for fn in sorted(os.listdir(root)):
+            with open(os.path.join(root, fn), 'rb') as f:
+                h.update(fn.encode())
+                h.update(f.read())
+    h.update(' '.join(FLAGS).encode())
+    return h.hexdigest()
+
+
+def is_current():
+    stamp_file = os.path.join(OBJ, 'stamp')
+    return os.path.exists(LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == _stamp()
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    stamp_file = os.path.join(OBJ, 'stamp')
+    if not force and is_current():
+        return LIB
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        obj = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
+        cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return obj
+
+    with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
+    with open(stamp_file, 'w') as f:
+        f.write(_stamp())
+    if verbose:
+        print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)')
+    return LIB
+
+
+if __name__ == '__main__':
+    build(force='--force' in sys.argv)

@@ -1,0 +1,175 @@
+// extern "C" surface of libsdmi (include/sdmi.h).  Thin: argument checks, struct translation, error capture.
+#include <string.h>
+
+#include <new>
+
+#include "prof.h"
+#include "unet.h"
+
+namespace sdmi {
+static thread_local std::string g_err;
+void set_error(const std::string& msg) { g_err = msg; }
+int fail(const std::string& msg) { g_err = msg; return -1; }
+}  // namespace sdmi
+
+struct sdmi_unet { sdmi::UNet impl; };
+
+using namespace sdmi;
+
+static void* g_zero_page[16] = {nullptr};
+static int zero_page(const f16** out) {
+  int dev = 0;
+  SDMI_HIP_OK(hipGetDevice(&dev));
+  SDMI_CHECK(dev >= 0 && dev < 16, "device index");
+  if (!g_zero_page[dev]) {
+    SDMI_HIP_OK(hipMalloc(&g_zero_page[dev], 4096));
+    SDMI_HIP_OK(hipMemset(g_zero_page[dev], 0, 4096));
+  }
+  *out = (const f16*)g_zero_page[dev];
+  return 0;
+}
+
+extern "C" {
+
+const char* sdmi_last_error(void) { return g_err.c_str(); }
+int sdmi_abi_version(void) { return SDMI_ABI_VERSION; }
+
+int sdmi_unet_create(const sdmi_unet_cfg* cfg, sdmi_unet** out) {
+  SDMI_CHECK(cfg && out, "null argument");
+  sdmi_unet* h = new (std::nothrow) sdmi_unet();
+  SDMI_CHECK(h != nullptr, "out of host memory");
+  if (h->impl.build(*cfg)) { delete h; return -1; }
+  *out = h;
+  return 0;
+}
+int sdmi_unet_destroy(sdmi_unet* h) { delete h; return 0; }
+int sdmi_unet_num_weights(const sdmi_unet* h) { return h ? (int)h->impl.slots().size() : fail("null handle"); }
+int sdmi_unet_weight_info(const sdmi_unet* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim) {
+  SDMI_CHECK(h && key_buf && shape4 && ndim, "null argument");
+  SDMI_CHECK(idx >= 0 && idx < (int)h->impl.slots().size(), "weight index out of range");
+  const WeightSlot& s = h->impl.slots()[idx];
+  SDMI_CHECK((int)s.key.size() + 1 <= key_buf_len, "key buffer too small");
+  memcpy(key_buf, s.key.c_str(), s.key.size() + 1);
+  *ndim = (int)s.shape.size();
+  for (int i = 0; i < 4; ++i) shape4[i] = i < *ndim ? s.shape[i] : 1;
+  return 0;
+}
+int sdmi_unet_set_weight(sdmi_unet* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream) {
+  SDMI_CHECK(h && key && ptr && shape, "null argument");
+  return h->impl.set_weight(key, ptr, shape, ndim, (hipStream_t)stream);
+}
+int sdmi_unet_finalize(sdmi_unet* h) { SDMI_CHECK(h, "null handle"); return h->impl.finalize(); }
+
+int64_t sdmi_unet_workspace_bytes(sdmi_unet* h, int B, int H, int W, int Lctx) {
+  if (!h) { fail("null handle"); return 0; }
+  int64_t need = 0;
+  if (h->impl.run(nullptr, nullptr, nullptr, nullptr, nullptr, B, H, W, Lctx, nullptr, 0, nullptr, true, false, &need)) return 0;
+  return need;
+}
+int sdmi_unet_cache_context(sdmi_unet* h, const float* ctx, int B, int Lctx, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+  SDMI_CHECK(h && ctx, "null argument");
+  const int down = 1 << (h->impl.cfg_.n_levels - 1);
+  return h->impl.run(nullptr, nullptr, nullptr, ctx, nullptr, B, down, down, Lctx, workspace, workspace_bytes,
+                     (hipStream_t)stream, false, true, nullptr);
+}
+int sdmi_unet_forward(sdmi_unet* h, const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx,
+                      float* eps_out, int B, int H, int W, int Lctx, void* workspace, int64_t workspace_bytes, void* stream) {
+  SDMI_CHECK(h && x && eps_out, "null argument");
+  SDMI_CHECK((t_i64 != nullptr) != (t_f32 != nullptr), "pass exactly one of t_i64 / t_f32");
+  return h->impl.run(x, t_i64, t_f32, ctx, eps_out, B, H, W, Lctx, workspace, workspace_bytes, (hipStream_t)stream, false,
+                     false, nullptr);
+}
+
+int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float* x, int mode, const float* old0,
+                      const float* old1, const float* old2, float a_t, float a_prev, float sigma, float sqrt_1m_at,
+                      const float* noise, float* e_t_out, float* x_prev, float* pred_x0, int64_t n, void* stream) {
+  SamplerStepParams p;
+  p.eps_model = eps_model; p.cfg = cfg; p.scale = scale; p.x = x; p.mode = mode;
+  p.old0 = old0; p.old1 = old1; p.old2 = old2;
+  p.a_t = a_t; p.a_prev = a_prev; p.sigma = sigma; p.sqrt_1m_at = sqrt_1m_at;
+  p.noise = noise; p.e_t_out = e_t_out; p.x_prev = x_prev; p.pred_x0 = pred_x0; p.n = n;
+  return launch_sampler_step(p, (hipStream_t)stream);
+}
+
+// ---- kernel-level entry points ------------------------------------------------------------------------
+int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
+  SDMI_CHECK(d, "null descriptor");
+  IGemmParams p;
+  p.a0 = (const f16*)d->a0; p.a1 = (const f16*)d->a1; p.c0 = d->c0; p.c1 = d->c1; p.lda0 = d->lda0; p.lda1 = d->lda1;
+  p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
+  p.ksize = d->ksize; p.stride = d->stride; p.up = d->up;
+  p.w = (const f16*)d->w; p.M = d->B * d->Hout * d->Wout; p.N = d->N; p.K = d->ksize * d->ksize * (d->c0 + d->c1);
+  p.mode = d->mode; p.bias = d->bias; p.rowvec = d->rowvec; p.ld_rowvec = d->ld_rowvec;
+  p.residual = d->residual; p.ldr = d->ldr; p.out_f32 = d->out_f32; p.out_f16 = (f16*)d->out_f16; p.ldo = d->ldo;
+  for (int i = 0; i < 3; ++i) { p.seg_dst[i] = (f16*)d->seg_dst[i]; p.seg_kind[i] = d->seg_kind[i]; }
+  p.heads = d->heads; p.dh = d->dh; p.ntok = d->ntok; p.ntok_pad = d->ntok_pad; p.segC = d->segC;
+  p.splitk = d->splitk;
+  if (zero_page(&p.zero_page)) return -1;
+  IGemmTune t; t.tile = d->tile; t.dma = d->dma;
+  return launch_igemm(p, t, (hipStream_t)stream);
+}
+int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
+                     int nkv_pad, int d, float scale, void* stream) {
+  AttnParams a;
+  a.q = (const f16*)q; a.k = (const f16*)k; a.vt = (const f16*)vt; a.out = (f16*)out;
+  a.BH = BH; a.heads = heads; a.nq = nq; a.nkv = nkv; a.nkv_pad = nkv_pad; a.d = d; a.scale = scale;
+  return launch_attention(a, (hipStream_t)stream);
+}
+int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { return gn_partial_floats(B, HW); }
+int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
+                     const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16,
+                     float* partial_ws, int64_t partial_floats, void* stream) {
+  SDMI_CHECK(partial_floats >= gn_partial_floats(B, HW), "groupnorm workspace too small");
+  GroupNormParams g;
+  g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = HW; g.gamma = gamma; g.beta = beta; g.eps = eps;
+  g.silu = silu; g.out_f16 = (f16*)out_f16; g.out_f32 = out_f32; g.raw_f16 = (f16*)raw_f16; g.partial = partial_ws;
+  return launch_groupnorm(g, (hipStream_t)stream);
+}
+int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
+                     void* stream) {
+  return launch_layernorm(x, gamma, beta, (f16*)out_f16, M, C, eps, (hipStream_t)stream);
+}
+int sdmi_k_cast_f16(const float* x, void* out_f16, int64_t n, void* stream) {
+  return launch_cast_f16(x, (f16*)out_f16, n, (hipStream_t)stream);
+}
+int sdmi_k_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, void* stream) {
+  return launch_timestep_embedding(t_i64, t_f32, out, B, dim, (hipStream_t)stream);
+}
+int sdmi_k_small_linear(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out, int B,
+                        int N, int K, int silu_in, void* stream) {
+  return launch_small_linear(in, ld_in, w, bias, out, ld_out, B, N, K, silu_in, (hipStream_t)stream);
+}
+int sdmi_k_conv_in(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
+                   void* stream) {
+  return launch_conv_in(x, w, bias, out, B, Cin, H, W, Cout, (hipStream_t)stream);
+}
+int sdmi_k_conv_out(const float* h, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+                    void* stream) {
+  return launch_conv_out(h, w, bias, out, B, H, W, Cin, Cout, (hipStream_t)stream);
+}
+int sdmi_k_pack_conv_weight(const float* w, void* dst, int O, int I, int KH, int KW, void* stream) {
+  return launch_pack_conv_weight(w, (f16*)dst, O, I, KH, KW, (hipStream_t)stream);
+}
+int sdmi_k_pack_conv_out(const float* w, float* dst, int O, int I, void* stream) {
+  return launch_pack_conv_out(w, dst, O, I, (hipStream_t)stream);
+}
+int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst, float* bdst, int N, int K, void* stream) {
+  return launch_pack_geglu(w, bias, (f16*)wdst, bdst, N, K, (hipStream_t)stream);
+}
+int sdmi_profile_begin(void) { return prof_begin(); }
+int sdmi_profile_end(char* buf, int buflen) {
+  SDMI_CHECK(buf && buflen > 2, "null buffer");
+  std::string js;
+  if (prof_end(&js)) return -1;
+  SDMI_CHECK((int)js.size() + 1 <= buflen, "profile buffer too small");
+  memcpy(buf, js.c_str(), js.size() + 1);
+  return 0;
+}
+const void* sdmi_zero_page(void) {
+  const f16* z = nullptr;
+  if (zero_page(&z)) return nullptr;
+  return z;
+}
+
+}  // extern "C"

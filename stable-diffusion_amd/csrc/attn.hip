@@ -1,0 +1,254 @@
+// Fused softmax(Q K^T * scale) V for the SpatialTransformer self- and cross-attention
+// (reference: CrossAttention.forward, ldm/modules/attention.py:170-193).
+// The reference materialises sim[(b h), N, Nkv]; this kernel keeps it in registers (online softmax).
+//
+// gfx950 design:
+//   * one wave owns 32 query rows; NW waves per workgroup share the K / V^T tiles (64 keys) staged in LDS,
+//     double buffered, register-staged (loads for tile t+1 are in flight while tile t is computed).
+//   * "swapped" product S^T = K Q^T on v_mfma_f32_32x32x16_f16: the accumulator layout then gives every lane
+//     one query column (q = lane & 31) and 16 of the 32 key rows, so the row max / row sum are in-lane
+//     reductions plus one cross-half exchange, and the O rescale factor is a per-lane scalar.
+//   * O^T = V^T P^T: the fp16-rounded probabilities are fed back as the MFMA B operand *straight from the
+//     accumulator registers*; the k-slot order of the contraction is permuted to match (lane half g, slot e
+//     <-> key 16*s + 8*(e>>2) + 4*g + (e&3)) and V^T fragments are read from LDS in that same order with
+//     two ds_read_b64 -- no cross-lane shuffles, no P round trip through LDS.
+//   * V is consumed transposed ([d][key], key-contiguous) -- the QKV projection epilogue (igemm EPI_HEADS)
+//     writes it that way, so no transpose happens here.
+//   * fp32 scores, max, sum and output accumulation; exp via v_exp_f32 on log2e-prescaled scores.
+#include "common.h"
+#include "prof.h"
+
+namespace sdmi {
+namespace {
+
+constexpr int KVT = 64;
+
+template <int D, int NW>
+__global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
+  constexpr int DKS = (D + 15) / 16;   // k-steps of 16 over the head dim (QK^T)
+  constexpr int DVT = (D + 31) / 32;   // 32-row tiles over the head dim (PV)
+  constexpr int NT = NW * 64;
+  constexpr int KSTRIDE = DKS * 32 + 16;          // bytes; odd multiple of 16 -> conflict-free ds_read_b128
+  constexpr int VSTRIDE = KVT * 2 + 8;            // bytes; 34 dwords -> conflict-free ds_read_b64
+  constexpr int KBYTES = KVT * KSTRIDE;
+  constexpr int VBYTES = DVT * 32 * VSTRIDE;
+  constexpr int STAGE = KBYTES + VBYTES;
+  constexpr int KCH = KVT * DKS * 2;              // 16-B chunks in a K tile
+  constexpr int VCH = DVT * 32 * (KVT / 8);       // 16-B chunks in a V^T tile
+  constexpr int KIT = (KCH + NT - 1) / NT;
+  constexpr int VIT = (VCH + NT - 1) / NT;
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l31 = lane & 31, lg = lane >> 5;
+  const int bh = blockIdx.y;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const f16* Qg = p.q + (size_t)bh * p.nq * D;
+  const f16* Kg = p.k + (size_t)bh * p.nkv * D;
+  const f16* Vg = p.vt + (size_t)bh * D * p.nkv_pad;
+
+  // Q^T fragments (MFMA B operand): lane (q = l31, g = lg) holds Q[q][16*ks + 8*g .. +8]
+  f16x8 qf[DKS];
+#pragma unroll
+  for (int ks = 0; ks < DKS; ++ks) {
+    const int dcol = ks * 16 + lg * 8;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q0 + l31 < p.nq && dcol < D) v = *(const f16x8*)(Qg + (size_t)(q0 + l31) * D + dcol);
+    qf[ks] = v;
+  }
+
+  f16x8 kreg[KIT], vreg[VIT];
+  auto load_tile = [&](int t) {
+    const int kv0 = t * KVT;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int c = tid + it * NT;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < KCH) {
+        const int row = c / (DKS * 2), col = c - row * (DKS * 2);
+        if (kv0 + row < p.nkv && col * 8 < D) v = *(const f16x8*)(Kg + (size_t)(kv0 + row) * D + col * 8);
+      }
+      kreg[it] = v;
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int c = tid + it * NT;
+      f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+      if (c < VCH) {
+        const int row = c / (KVT / 8), col = c - row * (KVT / 8);
+        if (row < D && kv0 + col * 8 < p.nkv_pad) v = *(const f16x8*)(Vg + (size_t)row * p.nkv_pad + kv0 + col * 8);
+      }
+      vreg[it] = v;
+    }
+  };
+  auto store_tile = [&](int stage) {
+    unsigned char* Ks = smem + stage * STAGE;
+    unsigned char* Vs = Ks + KBYTES;
+#pragma unroll
+    for (int it = 0; it < KIT; ++it) {
+      const int c = tid + it * NT;
+      if (c < KCH) {
+        const int row = c / (DKS * 2), col = c - row * (DKS * 2);
+        *(f16x8*)(Ks + row * KSTRIDE + col * 16) = kreg[it];
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < VIT; ++it) {
+      const int c = tid + it * NT;
+      if (c < VCH) {
+        const int row = c / (KVT / 8), col = c - row * (KVT / 8);
+        unsigned char* d = Vs + row * VSTRIDE + col * 16;
+        const f16x8 v = vreg[it];
+        *(f16x4*)(d) = f16x4{v[0], v[1], v[2], v[3]};
+        *(f16x4*)(d + 8) = f16x4{v[4], v[5], v[6], v[7]};
+      }
+    }
+  };
+
+  f32x16 o[DVT];
+#pragma unroll
+  for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;   // scores are compared / exponentiated in log2 units
+
+  const int nt = (p.nkv + KVT - 1) / KVT;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  for (int t = 0; t < nt; ++t) {
+    const int cur = t & 1;
+    const bool more = (t + 1 < nt);
+    if (more) load_tile(t + 1);
+    const unsigned char* Ks = smem + cur * STAGE;
+    const unsigned char* Vs = Ks + KBYTES;
+
+    // ---- S^T = K Q^T (two 32-key blocks) ----
+    f32x16 s[KVT / 32];
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kvb][r] = 0.f;
+      const unsigned char* kp = Ks + (kvb * 32 + l31) * KSTRIDE + lg * 16;
+#pragma unroll
+      for (int ks = 0; ks < DKS; ++ks) {
+        const f16x8 a = *(const f16x8*)(kp + ks * 32);
+        s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
+      }
+    }
+    // ---- mask keys beyond nkv (last tile only) ----
+    const int kv0 = t * KVT;
+    if (kv0 + KVT > p.nkv) {
+#pragma unroll
+      for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + kvb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (kv >= p.nkv) s[kvb][r] = -1e30f;
+        }
+    }
+    // ---- online softmax (per query = per lane column; halves lg = 0/1 hold disjoint keys) ----
+    float mx = -1e30f;
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sc);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kvb][r], sc, -m_new));
+        s[kvb][r] = pv;
+        psum += pv;
+      }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)s[kvb][8 * s2 + e];
+        const unsigned char* vp = Vs + l31 * VSTRIDE + (kvb * 32 + 16 * s2 + 4 * lg) * 2;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+          const f16x4 lo = *(const f16x4*)(vp + dt * 32 * VSTRIDE);
+          const f16x4 hi = *(const f16x4*)(vp + dt * 32 * VSTRIDE + 16);
+          const f16x8 a = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- normalise and store: O[b][q][head*D + dd] ----
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.nq) {
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    f16* orow = p.out + ((size_t)b * p.nq + q) * ((size_t)p.heads * D) + (size_t)head * D;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dd = dt * 32 + 8 * r4 + 4 * lg;
+        if (dd < D) {
+          f16x4 v = {(f16)(o[dt][r4 * 4 + 0] * inv), (f16)(o[dt][r4 * 4 + 1] * inv), (f16)(o[dt][r4 * 4 + 2] * inv),
+                     (f16)(o[dt][r4 * 4 + 3] * inv)};
+          *(f16x4*)(orow + dd) = v;
+        }
+      }
+  }
+}
+
+template <int D>
+int launch_d(const AttnParams& p, hipStream_t stream) {
+  const long bh = p.BH;
+  int nw = 8;
+  if ((long)cdiv(p.nq, 256) * bh < 256) nw = 4;
+  if ((long)cdiv(p.nq, 128) * bh < 256) nw = 2;
+  static const char* env = getenv("SDMI_ATTN_NW");
+  if (env) nw = atoi(env);
+  dim3 grid(cdiv(p.nq, 32 * nw), p.BH);
+  static const std::string pname = std::string("attn_d") + std::to_string(D);
+  ProfScope ps(pname.c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
+  if (nw == 8) hipLaunchKernelGGL((attn_kernel<D, 8>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) hipLaunchKernelGGL((attn_kernel<D, 4>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((attn_kernel<D, 2>), grid, dim3(128), 0, stream, p);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int launch_attention(const AttnParams& p, hipStream_t stream) {
+  SDMI_CHECK(p.BH > 0 && p.nq > 0 && p.nkv > 0 && p.heads > 0 && p.BH % p.heads == 0, "bad attention shape");
+  SDMI_CHECK(p.nkv_pad % 8 == 0 && p.nkv_pad >= p.nkv, "nkv_pad must be a multiple of 8 and >= nkv");
+  switch (p.d) {
+    case 32: return launch_d<32>(p, stream);
+    case 40: return launch_d<40>(p, stream);
+    case 64: return launch_d<64>(p, stream);
+    case 80: return launch_d<80>(p, stream);
+    case 128: return launch_d<128>(p, stream);
+    case 160: return launch_d<160>(p, stream);
+    default: return fail("attention head dim " + std::to_string(p.d) + " not instantiated (32/40/64/80/128/160)");
+  }
+}
+
+}  // namespace sdmi

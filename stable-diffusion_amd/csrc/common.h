@@ -1,0 +1,144 @@
+// Shared device/host helpers for the MI355X (gfx950) kernels of libsdmi.
+// wave = 64 lanes, MFMA 32x32x16 f16 -> f32, LDS tiles read as ds_read_b128.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace sdmi {
+
+// thread-local error text surfaced through sdmi_last_error()
+void set_error(const std::string& msg);
+int fail(const std::string& msg);   // sets the error, returns -1
+
+#define SDMI_HIP_OK(expr)                                                                    \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess)                                                                    \
+      return ::sdmi::fail(std::string(#expr) + ": " + hipGetErrorString(_e));                \
+  } while (0)
+
+#define SDMI_CHECK(cond, msg)                                                                \
+  do {                                                                                       \
+    if (!(cond)) return ::sdmi::fail(std::string("check failed: ") + #cond + " -- " + (msg)); \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+
+// ----------------------------------------------------------------------------------------------
+// Implicit-GEMM descriptor:  out[M,N] (+epilogue) = gatherA[M,K] * W[N,K]^T
+//   A is fp16 NHWC activations (one or two channel-concatenated sources), gathered as a
+//   1x1 or 3x3 (stride 1/2, optional nearest-x2 upsampled input) convolution; a Linear is ksize=1.
+//   W is fp16 [N][K], K ordered (ky, kx, cin)  -- packed once by pack.hip.
+// ----------------------------------------------------------------------------------------------
+enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
+
+struct IGemmParams {
+  const f16* a0 = nullptr; const f16* a1 = nullptr;   // A sources (a1 optional: channel concat [a0 | a1])
+  int c0 = 0, c1 = 0;                                  // channels taken from each source (Cin = c0 + c1)
+  int lda0 = 0, lda1 = 0;                              // row pitch (elements) of each source
+  int B = 1, Hin = 1, Win = 1;                         // source spatial dims (M = B*Hout*Wout)
+  int Hout = 1, Wout = 1;
+  int ksize = 1, stride = 1, up = 0;
+  const f16* w = nullptr;                              // [N][K]
+  int M = 0, N = 0, K = 0;
+  // epilogue
+  int mode = EPI_PLAIN;
+  const float* bias = nullptr;                         // [N]
+  const float* rowvec = nullptr; int ld_rowvec = 0;    // per-batch vector [B][ld_rowvec] added to every row of batch b
+  const float* residual = nullptr; int ldr = 0;        // fp32 [M][ldr]
+  float* out_f32 = nullptr; f16* out_f16 = nullptr; int ldo = 0;   // either / both
+  // EPI_HEADS: N = nseg * C, column n -> segment n / C, head (n % C) / dh, dd = n % dh
+  //   seg_kind 0: row layout   dst[((b*heads + head) * ntok + tok) * dh + dd]
+  //   seg_kind 1: transposed   dst[((b*heads + head) * dh + dd) * ntok_pad + tok]
+  f16* seg_dst[3] = {nullptr, nullptr, nullptr};
+  int seg_kind[3] = {0, 0, 0};
+  int heads = 0, dh = 0, ntok = 0, ntok_pad = 0, segC = 0;
+  // split-K: >1 => fp32 atomicAdd into out_f32 (which the caller pre-initialised with the epilogue terms)
+  int splitk = 1;
+  const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
+};
+
+struct IGemmTune {        // runtime knobs (tests sweep them; the executor picks by heuristic)
+  int tile = -1;          // -1 auto, 0: 128x128, 1: 128x64, 2: 64x64
+  int dma = -1;           // -1 default, 0 register-staged loads, 1 global_load_lds
+};
+
+int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream);
+
+// Flash attention over per-head layouts produced by EPI_HEADS
+struct AttnParams {
+  const f16* q = nullptr;    // [BH][nq][d]
+  const f16* k = nullptr;    // [BH][nkv][d]
+  const f16* vt = nullptr;   // [BH][d][nkv_pad]   (nkv_pad = round_up(nkv, 8), pad tokens zero)
+  f16* out = nullptr;        // [B][nq][heads*d]  (heads merged, '(b h) n d -> b n (h d)')
+  int BH = 0, heads = 0, nq = 0, nkv = 0, nkv_pad = 0, d = 0;
+  float scale = 1.f;
+};
+int launch_attention(const AttnParams& p, hipStream_t stream);
+
+// GroupNorm(32) (+SiLU) over fp32 NHWC, channel-concat of two sources, fp16 or fp32 output
+struct GroupNormParams {
+  const float* x0 = nullptr; const float* x1 = nullptr; int c0 = 0, c1 = 0;
+  int B = 0, HW = 0;
+  const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-5f;
+  int silu = 0;
+  f16* out_f16 = nullptr;      // [B*HW][C] normalised (+SiLU)
+  float* out_f32 = nullptr;    // same in fp32 (used by the output head)
+  f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
+  float* partial = nullptr;    // workspace [B][nchunk][32][2]
+};
+int gn_partial_floats(int B, int HW);
+int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,
+                     hipStream_t stream);
+int launch_cast_f16(const float* x, f16* out, int64_t n, hipStream_t stream);
+
+// fp32 "small" path
+int launch_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, hipStream_t s);
+int launch_small_linear(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out,
+                        int B, int N, int K, int silu_in, hipStream_t s);
+int launch_conv_in(const float* x_nchw, const float* w, const float* bias, float* out_nhwc, int B, int Cin, int H,
+                   int W, int Cout, hipStream_t s);
+int launch_conv_out(const float* h_nhwc, const float* w_khwc, const float* bias, float* out_nchw, int B, int H, int W,
+                    int Cin, int Cout, hipStream_t s);
+// out = bias[n] + rowvec[b][n] + residual   (pre-initialisation for split-K atomics)
+int launch_epilogue_init(float* out, int ldo, const float* bias, const float* rowvec, int ld_rowvec,
+                         const float* residual, int ldr, int M, int N, int rows_per_batch, hipStream_t s);
+
+// weight packing (device pointers, fp32 reference layouts -> packed)
+int launch_pack_conv_weight(const float* w_oihw, f16* dst, int O, int I, int KH, int KW, hipStream_t s);  // -> [O][KH][KW][I]
+int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0, int dst_ld, hipStream_t s);
+int launch_pack_geglu(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K, hipStream_t s);
+int launch_pack_conv_out(const float* w_oihw, float* dst, int O, int I, hipStream_t s);   // -> [O][3][3][I] fp32
+
+// sampler update (fp32): see sampler.hip
+struct SamplerStepParams {
+  const float* eps_model = nullptr;  // model output: rows [0,n) uncond, [n,2n) cond when cfg, else [0,n)
+  int cfg = 0; float scale = 1.f;    // e_t = e_u + scale * (e_c - e_u)                      plms.py:182-186
+  const float* x = nullptr;          // [B,4,H,W] current latent
+  // multistep combination (plms.py:218-232), evaluated in the reference's fp32 operation order:
+  //   0: e' = e_t                      (DDIM, ddim.py:189-204)
+  //   1: e' = (3 e_t - o0) / 2         2: e' = (23 e_t - 16 o0 + 5 o1) / 12
+  //   3: e' = (55 e_t - 59 o0 + 37 o1 - 9 o2) / 24
+  //   4: e' = (o0 + e_t) / 2           (first PLMS step: o0 = e_t, e_t = e_t_next)
+  int mode = 0;
+  const float* old0 = nullptr; const float* old1 = nullptr; const float* old2 = nullptr;  // newest first
+  float a_t = 1.f, a_prev = 1.f, sigma = 0.f, sqrt_1m_at = 0.f;                           // table entries
+  const float* noise = nullptr;      // optional [B,4,H,W] (sigma > 0), already scaled by temperature
+  float* e_t_out = nullptr;          // optional: combined (post-CFG) eps, kept for the history
+  float* x_prev = nullptr; float* pred_x0 = nullptr;   // pred_x0 optional
+  int64_t n = 0;                     // elements per output (B*4*H*W)
+};
+int launch_sampler_step(const SamplerStepParams& p, hipStream_t s);
+
+}  // namespace sdmi

@@ -1,0 +1,378 @@
+// Implicit-GEMM convolution / linear kernel for gfx950 (MI355X).
+//
+//   out[M,N] = epilogue( gatherA[M,K] * W[N,K]^T )
+//
+// Replaces the reference's F.conv2d / F.linear call sites on the UNet hot path
+// (ldm/modules/diffusionmodules/openaimodel.py:204,230,241,150-153,116-118 and
+//  ldm/modules/attention.py:161-168,40,58,233-248) -- SURVEY.md K4-K9, K11, K14.
+//
+// Design (wave64, MFMA v_mfma_f32_32x32x16_f16, fp32 accumulate):
+//   * A (activations, fp16 NHWC) is gathered on the fly: 1x1 / 3x3, stride 1/2, nearest-x2 upsample
+//     folded into the index math, two channel-concatenated sources (UNet skip concat) -- nothing is
+//     materialised.  Out-of-image taps read a zero page.
+//   * k-tile = 64 halves; both operands are staged as [rows][128 B] LDS tiles, double buffered, either by
+//     LDS-DMA (global_load_lds_dwordx4: wave-uniform LDS base + lane*16, per-lane global source) or through
+//     registers.  16-byte chunks are XOR-swizzled with ((row>>1)&7) so the ds_read_b128 fragment reads of
+//     any 16 rows that differ mod 16 are bank-conflict free; with DMA the swizzle is applied to the
+//     per-lane *source* chunk and to the read address (LDS destination stays linear).
+//   * one barrier per k-tile: loads for tile t+1 are issued right after the barrier and land while the
+//     MFMAs of tile t run.
+//   * epilogues: +bias[n] +rowvec[batch][n] (time-embedding add) +fp32 residual, fp32 and/or fp16 store;
+//     GEGLU (value * gelu_erf(gate), weights pre-interleaved in 32-row groups); per-head scatter of
+//     q / k / v^T for the attention kernel; split-K via fp32 atomics onto a pre-initialised output.
+//   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles.
+#include "common.h"
+#include "prof.h"
+
+namespace sdmi {
+
+namespace {
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGemmParams p, const int tiles_m,
+                                                                       const int tiles_n, const int kt_per_split) {
+  constexpr int NT = WARPS_M * WARPS_N * 64;
+  constexpr int RPP = NT / 8;  // rows per load pass (8 chunks of 16 B per 128-B row)
+  constexpr int A_PASSES = BM / RPP;
+  constexpr int B_PASSES = BN / RPP;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  static_assert(A_PASSES >= 1 && B_PASSES >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
+  static_assert(RPP % 16 == 0, "swizzle assumes pass offset keeps row bits 1..3");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+
+  // ---- XCD-aware tile assignment (dispatcher places block b on XCD b % 8; speed only) ----------------
+  const int nblk = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles_mn = tiles_m * tiles_n;
+  const int split = wgid / tiles_mn;
+  const int tmn = wgid - split * tiles_mn;
+  const int tile_n = tmn / tiles_m;
+  const int tile_m = tmn - tile_n * tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nkt = p.K / BK;
+  const int kt_begin = split * kt_per_split;
+  const int kt_end = min(nkt, kt_begin + kt_per_split);
+  if (kt_begin >= kt_end) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int cpos = tid & 7;                      // chunk position inside the LDS row
+  const int lrow = tid >> 3;                     // row inside a load pass
+  const int gch = cpos ^ ((lrow >> 1) & 7);      // global chunk that lands at (row, cpos)
+
+  // ---- per-row gather metadata ---------------------------------------------------------------------
+  const int HWout = p.Hout * p.Wout;
+  const int Cin = p.c0 + p.c1;
+  const int pad = (p.ksize == 3) ? 1 : 0;
+  const int Hv = p.up ? 2 * p.Hin : p.Hin;
+  const int Wv = p.up ? 2 * p.Win : p.Win;
+  int a_pb[A_PASSES], a_oy[A_PASSES], a_ox[A_PASSES];
+#pragma unroll
+  for (int i = 0; i < A_PASSES; ++i) {
+    const int m = m0 + i * RPP + lrow;
+    if (m < p.M) {
+      const int b = m / HWout;
+      const int rem = m - b * HWout;
+      const int oy = rem / p.Wout;
+      a_pb[i] = b * p.Hin * p.Win;
+      a_oy[i] = oy * p.stride - pad;
+      a_ox[i] = (rem - oy * p.Wout) * p.stride - pad;
+    } else {
+      a_pb[i] = -1; a_oy[i] = 0; a_ox[i] = 0;
+    }
+  }
+  const f16* b_ptr[B_PASSES];
+#pragma unroll
+  for (int i = 0; i < B_PASSES; ++i) {
+    const int n = n0 + i * RPP + lrow;
+    b_ptr[i] = (n < p.N) ? (p.w + (size_t)n * p.K + gch * 8) : nullptr;
+  }
+
+  f16x8 regA[DMA ? 1 : A_PASSES], regB[DMA ? 1 : B_PASSES];
+
+  auto issue_loads = [&](int kt, int stage) {
+    const int k0 = kt * BK;
+    const int tap = k0 / Cin;
+    const int cin0 = k0 - tap * Cin;
+    const int ky = (p.ksize == 3) ? tap / 3 : 0;
+    const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
+    const f16* src; int ld, coff;
+    if (cin0 < p.c0) { src = p.a0; ld = p.lda0; coff = cin0; } else { src = p.a1; ld = p.lda1; coff = cin0 - p.c0; }
+    unsigned char* As = smem + stage * STAGE_BYTES;
+    unsigned char* Bs = As + BM * 128;
+#pragma unroll
+    for (int i = 0; i < A_PASSES; ++i) {
+      const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
+      const bool ok = (a_pb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
+      const int sy = p.up ? (iy >> 1) : iy, sx = p.up ? (ix >> 1) : ix;
+      const f16* g = ok ? (src + (size_t)(a_pb[i] + sy * p.Win + sx) * ld + coff + gch * 8) : p.zero_page;
+      if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(As + (i * RPP + wave * 8) * 128), 16,
+                                         0, 0);
+      } else {
+        regA[i] = *(const f16x8*)g;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < B_PASSES; ++i) {
+      const f16* g = b_ptr[i] ? (b_ptr[i] + k0) : p.zero_page;
+      if constexpr (DMA) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * RPP + wave * 8) * 128), 16,
+                                         0, 0);
+      } else {
+        regB[i] = *(const f16x8*)g;
+      }
+    }
+  };
+  auto commit_regs = [&](int stage) {   // register-staged path: write the prefetched tile into LDS
+    if constexpr (!DMA) {
+      unsigned char* As = smem + stage * STAGE_BYTES;
+      unsigned char* Bs = As + BM * 128;
+#pragma unroll
+      for (int i = 0; i < A_PASSES; ++i) *(f16x8*)(As + (i * RPP + lrow) * 128 + cpos * 16) = regA[i];
+#pragma unroll
+      for (int i = 0; i < B_PASSES; ++i) *(f16x8*)(Bs + (i * RPP + lrow) * 128 + cpos * 16) = regB[i];
+    }
+  };
+
+  // ---- main loop -----------------------------------------------------------------------------------
+  const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+  const int l31 = lane & 31, lg = lane >> 5;
+  const int rsw = (l31 >> 1) & 7;
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  issue_loads(kt_begin, 0);
+  commit_regs(0);
+  for (int kt = kt_begin; kt < kt_end; ++kt) {
+    const int cur = (kt - kt_begin) & 1;
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const bool more = (kt + 1 < kt_end);
+    if (more) issue_loads(kt + 1, cur ^ 1);
+    const unsigned char* As = smem + cur * STAGE_BYTES + (wm * WTM + l31) * 128;
+    const unsigned char* Bs = smem + cur * STAGE_BYTES + BM * 128 + (wn * WTN + l31) * 128;
+#pragma unroll
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      const int coff = (((ks * 2 + lg) ^ rsw) << 4);
+      f16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(As + i * 32 * 128 + coff);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b[j] = *(const f16x8*)(Bs + j * 32 * 128 + coff);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    if (more) commit_regs(cur ^ 1);
+  }
+
+  // ---- epilogue ------------------------------------------------------------------------------------
+  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+  if (p.mode == EPI_PLAIN) {
+    const bool atomic = p.splitk > 1;
+    float bias_v[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + j * 32 + l31;
+      bias_v[j] = (!atomic && p.bias && n < p.N) ? p.bias[n] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+        if (m >= p.M) continue;
+        const float* rv = (!atomic && p.rowvec) ? (p.rowvec + (size_t)(m / HWout) * p.ld_rowvec) : nullptr;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = nw + j * 32 + l31;
+          if (n >= p.N) continue;
+          float v = acc[i][j][r];
+          if (atomic) {
+            unsafeAtomicAdd(p.out_f32 + (size_t)m * p.ldo + n, v);
+          } else {
+            v += bias_v[j];
+            if (rv) v += rv[n];
+            if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+            if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
+            if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
+          }
+        }
+      }
+    }
+  } else if (p.mode == EPI_GEGLU) {
+    if constexpr (TN % 2 == 0) {
+#pragma unroll
+      for (int j2 = 0; j2 < TN / 2; ++j2) {
+        const int nv = nw + (2 * j2) * 32 + l31;      // value column (packed order), gate = nv + 32
+        if (nv >= p.N) continue;
+        const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[nv + 32] : 0.f;
+        const int oc = (nw >> 1) + j2 * 32 + l31;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+            if (m >= p.M) continue;
+            const float val = acc[i][2 * j2][r] + bv;
+            const float gate = acc[i][2 * j2 + 1][r] + bg;
+            p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
+          }
+      }
+    }
+  } else {  // EPI_HEADS
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + j * 32 + l31;
+      if (n >= p.N) continue;
+      const int seg = n / p.segC;
+      const int c = n - seg * p.segC;
+      const int head = c / p.dh;
+      const int dd = c - head * p.dh;
+      f16* dst = p.seg_dst[seg];
+      const int kind = p.seg_kind[seg];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (m >= p.M) continue;
+          const int b = m / p.ntok;
+          const int tok = m - b * p.ntok;
+          const size_t bh = (size_t)b * p.heads + head;
+          const size_t off = kind == 0 ? ((bh * p.ntok + tok) * p.dh + dd) : ((bh * p.dh + dd) * p.ntok_pad + tok);
+          dst[off] = (f16)acc[i][j][r];
+        }
+    }
+  }
+}
+
+__global__ void epilogue_init_kernel(float* out, int ldo, const float* bias, const float* rowvec, int ld_rowvec,
+                                     const float* residual, int ldr, int M, int N, int rows_per_batch) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)M * (N / 4);
+  if (idx >= total) return;
+  const int m = (int)(idx / (N / 4));
+  const int n = (int)(idx - (int64_t)m * (N / 4)) * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (bias) v += *(const f32x4*)(bias + n);
+  if (rowvec) v += *(const f32x4*)(rowvec + (size_t)(m / rows_per_batch) * ld_rowvec + n);
+  if (residual) v += *(const f32x4*)(residual + (size_t)m * ldr + n);
+  *(f32x4*)(out + (size_t)m * ldo + n) = v;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
+  const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
+  const int nkt = p.K / BK;
+  const int kt_per_split = cdiv(nkt, splitk);
+  const int nsplit = cdiv(nkt, kt_per_split);
+  IGemmParams q = p;
+  q.splitk = nsplit;
+  dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
+  static const std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN);
+  const double src_pix = (double)p.B * p.Hin * p.Win;
+  const double out_b = (p.out_f32 ? 4.0 : 0.0) + ((p.out_f16 || p.mode != EPI_PLAIN) ? 2.0 : 0.0);
+  const double n_out = p.mode == EPI_GEGLU ? p.N / 2.0 : (double)p.N;
+  ProfScope ps(pname.c_str(), 2.0 * p.M * (double)p.N * p.K,
+               src_pix * (p.c0 + p.c1) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * n_out * out_b +
+                   (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
+               stream);
+  if (dma)
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true>), grid, block, 0, stream, q, tiles_m, tiles_n,
+                       kt_per_split);
+  else
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false>), grid, block, 0, stream, q, tiles_m, tiles_n,
+                       kt_per_split);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+int launch_epilogue_init(float* out, int ldo, const float* bias, const float* rowvec, int ld_rowvec,
+                         const float* residual, int ldr, int M, int N, int rows_per_batch, hipStream_t s) {
+  SDMI_CHECK(N % 4 == 0 && ldo % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "epilogue_init needs N % 4 == 0");
+  const int64_t total = (int64_t)M * (N / 4);
+  hipLaunchKernelGGL(epilogue_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, ldo, bias,
+                     rowvec, ld_rowvec, residual, ldr, M, N, rows_per_batch);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
+int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream) {
+  SDMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
+  SDMI_CHECK(p.ksize == 1 || p.ksize == 3, "ksize must be 1 or 3");
+  const int Cin = p.c0 + p.c1;
+  SDMI_CHECK(p.K == p.ksize * p.ksize * Cin, "K != ksize^2 * (c0 + c1)");
+  SDMI_CHECK(Cin % BK == 0 && p.c0 % BK == 0, "channel counts must be multiples of 64");
+  SDMI_CHECK(p.lda0 % 8 == 0 && (p.a1 == nullptr || p.lda1 % 8 == 0), "A row pitch must be a multiple of 8 halves");
+  SDMI_CHECK(p.zero_page != nullptr, "zero page missing");
+  SDMI_CHECK(p.M == p.B * p.Hout * p.Wout, "M != B * Hout * Wout");
+  SDMI_CHECK(p.c1 == 0 || p.a1 != nullptr, "second A source missing");
+  if (p.mode == EPI_GEGLU) SDMI_CHECK(p.N % 64 == 0 && p.out_f16 != nullptr, "GEGLU needs N % 64 == 0 and an fp16 output");
+  if (p.mode == EPI_HEADS) SDMI_CHECK(p.segC > 0 && p.dh > 0 && p.N % p.segC == 0 && p.N / p.segC <= 3, "bad head scatter");
+
+  static const int env_dma = env_int("SDMI_IGEMM_DMA", 1);
+  static const int env_tile = env_int("SDMI_IGEMM_TILE", -1);
+  const bool dma = (tune.dma >= 0 ? tune.dma : env_dma) != 0;
+  int tile = tune.tile >= 0 ? tune.tile : env_tile;
+  if (p.mode == EPI_GEGLU) tile = 0;
+  if (tile < 0) {
+    const long b0 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
+    const long b1 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
+    if (b0 >= 224) tile = 0;
+    else if (b1 >= 224) tile = 1;
+    else tile = 2;
+  }
+  const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64};
+  int splitk = p.splitk;
+  const int nkt = p.K / BK;
+  if (splitk <= 0) {  // auto
+    splitk = 1;
+    if (p.mode == EPI_PLAIN && p.out_f32 && !p.out_f16) {
+      const long blocks = (long)cdiv(p.M, BMs[tile]) * cdiv(p.N, BNs[tile]);
+      while (blocks * splitk < 256 && nkt / (splitk * 2) >= 4 && splitk < 16) splitk *= 2;
+    }
+  }
+  if (splitk > 1) {
+    SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && !p.out_f16, "split-K needs a plain fp32-only output");
+    SDMI_CHECK(p.N % 4 == 0, "split-K needs N % 4 == 0");
+    if (launch_epilogue_init(p.out_f32, p.ldo, p.bias, p.rowvec, p.ld_rowvec, p.residual, p.ldr, p.M, p.N,
+                             p.Hout * p.Wout, stream))
+      return -1;
+  }
+  switch (tile) {
+    case 0: return launch_cfg<128, 128, 2, 2>(p, dma, splitk, stream);
+    case 1: return launch_cfg<128, 64, 2, 2>(p, dma, splitk, stream);
+    case 2: return launch_cfg<64, 64, 2, 2>(p, dma, splitk, stream);
+    default: return fail("unknown igemm tile id");
+  }
+}
+
+}  // namespace sdmi

@@ -1,0 +1,186 @@
+// GroupNorm(32)(+SiLU), LayerNorm and fp32->fp16 cast over NHWC activations (HBM-bound kernels).
+//
+// Reference sites: GroupNorm32 (ldm/modules/diffusionmodules/util.py:199-216, eps 1e-5, used in
+// openaimodel.py:201-203,225-227,683-684), SpatialTransformer.norm (ldm/modules/attention.py:76-77, eps 1e-6),
+// LayerNorm x3 per BasicTransformerBlock (attention.py:203-205).  Statistics are fp32 (combined in fp64);
+// the normalised value is rounded to fp16 exactly once -- it is the MFMA A operand of the following conv / GEMM.
+// The UNet skip concat (openaimodel.py:736) is folded in: the kernels read two channel-concatenated sources.
+#include "common.h"
+#include "prof.h"
+
+namespace sdmi {
+namespace {
+
+constexpr int GN_CHUNK = 64;    // pixels per statistics block
+constexpr int GN_MAXC = 2560 * 2;
+
+__device__ __forceinline__ f32x4 load_cat4(const float* x0, const float* x1, int c0, int c1, size_t pix, int c) {
+  return (c < c0) ? *(const f32x4*)(x0 + pix * c0 + c) : *(const f32x4*)(x1 + pix * c1 + (c - c0));
+}
+
+// partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g)
+__global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk) {
+  __shared__ float csum[GN_MAXC], csq[GN_MAXC];
+  const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+  const int C = p.c0 + p.c1;
+  const int pix0 = chunk * GN_CHUNK;
+  const int npix = min(GN_CHUNK, p.HW - pix0);
+  for (int q = tid; q < C / 4; q += 256) {
+    const int c = q * 4;
+    f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+    for (int i = 0; i < npix; ++i) {
+      const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + i, c);
+      s += v;
+      ss += v * v;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { csum[c + j] = s[j]; csq[c + j] = ss[j]; }
+  }
+  __syncthreads();
+  if (tid < 32) {
+    const int cpg = C / 32;
+    float s = 0.f, ss = 0.f;
+    for (int j = 0; j < cpg; ++j) { s += csum[tid * cpg + j]; ss += csq[tid * cpg + j]; }
+    float* dst = p.partial + ((size_t)(b * nchunk + chunk) * 32 + tid) * 2;
+    dst[0] = s; dst[1] = ss;
+  }
+}
+
+constexpr int GN_APPLY_PIX = 8;
+
+__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nchunk) {
+  __shared__ float s_mean[32], s_rstd[32];
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const int C = p.c0 + p.c1;
+  const int cpg = C / 32;
+  if (tid < 32) {
+    double s = 0.0, ss = 0.0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const float* src = p.partial + ((size_t)(b * nchunk + ch) * 32 + tid) * 2;
+      s += (double)src[0]; ss += (double)src[1];
+    }
+    const double n = (double)cpg * (double)p.HW;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    s_mean[tid] = (float)mean;
+    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+  __syncthreads();
+  const int pix0 = blockIdx.x * GN_APPLY_PIX;
+  const int npix = min(GN_APPLY_PIX, p.HW - pix0);
+  const int nq = C / 4;
+  for (int idx = tid; idx < npix * nq; idx += 256) {
+    const int pi = idx / nq;
+    const int c = (idx - pi * nq) * 4;
+    const size_t pix = (size_t)b * p.HW + pix0 + pi;
+    const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, pix, c);
+    const f32x4 ga = *(const f32x4*)(p.gamma + c);
+    const f32x4 be = *(const f32x4*)(p.beta + c);
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int g = (c + j) / cpg;
+      float t = (v[j] - s_mean[g]) * s_rstd[g] * ga[j] + be[j];
+      if (p.silu) t = t / (1.0f + __expf(-t));
+      y[j] = t;
+    }
+    const size_t o = pix * C + c;
+    if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+    if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
+    if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  }
+}
+
+// one wave per row
+template <int MAXQ>
+__global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const float* gamma, const float* beta, f16* out,
+                                                        int M, int C, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* xr = x + (size_t)row * C;
+  f32x4 v[MAXQ];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) { v[i] = *(const f32x4*)(xr + c); s += v[i][0] + v[i][1] + v[i][2] + v[i][3]; }
+    else v[i] = f32x4{0, 0, 0, 0};
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float ss = 0.f;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; ss += d * d; }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
+  const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
+  f16* orow = out + (size_t)row * C;
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int c = (i * 64 + lane) * 4;
+    if (c < C) {
+      const f32x4 ga = *(const f32x4*)(gamma + c);
+      const f32x4 be = *(const f32x4*)(beta + c);
+      f16x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = (f16)((v[i][j] - mean) * rstd * ga[j] + be[j]);
+      *(f16x4*)(orow + c) = y;
+    }
+  }
+}
+
+__global__ void cast_f16_kernel(const float* x, f16* out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = *(const f32x4*)(x + i * 4);
+  *(f16x4*)(out + i * 4) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+}
+
+}  // namespace
+
+int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64; }
+
+int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
+  const int C = p.c0 + p.c1;
+  SDMI_CHECK(C % 32 == 0 && C <= GN_MAXC && p.c0 % 4 == 0 && p.c1 % 4 == 0, "GroupNorm(32) channel constraint");
+  SDMI_CHECK(p.partial != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
+  SDMI_CHECK(p.c1 == 0 || p.x1 != nullptr, "GroupNorm: second source missing");
+  const int nchunk = cdiv(p.HW, GN_CHUNK);
+  const double nel = (double)p.B * p.HW * C;
+  ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, nchunk);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,
+                     hipStream_t stream) {
+  SDMI_CHECK(C % 4 == 0 && C <= 2560, "LayerNorm: C must be a multiple of 4 and <= 2560");
+  dim3 grid(cdiv(M, 4)), block(256);
+  ProfScope ps("layernorm", 0.0, (double)M * C * 6.0, stream);
+  if (C <= 1280) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps);
+  else hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_cast_f16(const float* x, f16* out, int64_t n, hipStream_t stream) {
+  SDMI_CHECK(n % 4 == 0, "cast: n % 4 != 0");
+  const int64_t n4 = n / 4;
+  ProfScope ps("cast_f16", 0.0, (double)n * 6.0, stream);
+  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, out, n4);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sdmi

@@ -1,0 +1,274 @@
+// The fp32 "small" path of the UNet: everything whose cost is negligible but whose rounding is not.
+//   * sinusoidal timestep embedding + time_embed MLP + the 22 ResBlock emb_layers
+//     (ldm/modules/diffusionmodules/util.py:151-171, openaimodel.py:506-511,218-224) -- M = batch rows, GEMV-like,
+//     weight-bandwidth bound, kept in fp32.
+//   * the 4->C input conv and the C->4 output conv (openaimodel.py:519,685): K = 36 resp. N = 4, useless for MFMA;
+//     they also fold the NCHW<->NHWC layout change at the library boundary.
+//   * weight packing kernels (reference layouts -> fp16 [N][K] with K = (ky,kx,cin)).
+#include "common.h"
+#include "prof.h"
+#include <math.h>
+#include <vector>
+
+namespace sdmi {
+namespace {
+
+__global__ void temb_kernel(const int64_t* t_i64, const float* t_f32, const float* freqs, float* out, int B, int dim) {
+  const int half = dim / 2;
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * half) return;
+  const int b = idx / half, i = idx - b * half;
+  const float t = t_i64 ? (float)t_i64[b] : t_f32[b];
+  const float arg = t * freqs[i];
+  out[(size_t)b * dim + i] = cosf(arg);
+  out[(size_t)b * dim + half + i] = sinf(arg);
+  if ((dim & 1) && i == 0) out[(size_t)b * dim + dim - 1] = 0.f;
+}
+
+constexpr int SL_MAXB = 8;
+// one wave per output feature n: out[b][n] = bias[n] + sum_k W[n][k] * f(in[b][k]),  f = SiLU or identity
+__global__ void __launch_bounds__(256) small_linear_kernel(const float* in, int ld_in, const float* w, const float* bias,
+                                                           float* out, int ld_out, int B, int N, int K, int silu_in) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  float acc[SL_MAXB];
+#pragma unroll
+  for (int b = 0; b < SL_MAXB; ++b) acc[b] = 0.f;
+  const float* wr = w + (size_t)n * K;
+  for (int k = lane * 4; k < K; k += 256) {
+    const f32x4 wv = *(const f32x4*)(wr + k);
+#pragma unroll
+    for (int b = 0; b < SL_MAXB; ++b) {
+      if (b < B) {
+        f32x4 xv = *(const f32x4*)(in + (size_t)b * ld_in + k);
+        if (silu_in) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xv[j] = xv[j] / (1.0f + expf(-xv[j]));
+        }
+        acc[b] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < SL_MAXB; ++b) {
+    if (b < B) {
+      float v = acc[b];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) out[(size_t)b * ld_out + n] = v + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
+constexpr int CI_PIX = 16;
+constexpr int CI_MAXK = 9 * 16;   // Cin <= 16
+// x NCHW fp32 -> out NHWC fp32, 3x3 pad 1
+__global__ void __launch_bounds__(256) conv_in_kernel(const float* x, const float* w, const float* bias, float* out, int B,
+                                                      int Cin, int H, int W, int Cout) {
+  __shared__ float patch[CI_PIX][CI_MAXK];
+  const int tid = threadIdx.x;
+  const int K = Cin * 9;
+  const int M = B * H * W;
+  const int m0 = blockIdx.x * CI_PIX;
+  for (int idx = tid; idx < CI_PIX * K; idx += 256) {
+    const int pi = idx / K, k = idx - pi * K;      // k = ci*9 + ky*3 + kx  (OIHW order of the reference weight)
+    const int m = m0 + pi;
+    float v = 0.f;
+    if (m < M) {
+      const int b = m / (H * W), rem = m - b * H * W, y = rem / W, xx = rem - y * W;
+      const int ci = k / 9, t = k - ci * 9, ky = t / 3, kx = t - ky * 3;
+      const int iy = y + ky - 1, ix = xx + kx - 1;
+      if (iy >= 0 && iy < H && ix >= 0 && ix < W) v = x[(((size_t)b * Cin + ci) * H + iy) * W + ix];
+    }
+    patch[pi][k] = v;
+  }
+  __syncthreads();
+  for (int co = tid; co < Cout; co += 256) {
+    float acc[CI_PIX];
+    const float bv = bias ? bias[co] : 0.f;
+#pragma unroll
+    for (int pi = 0; pi < CI_PIX; ++pi) acc[pi] = bv;
+    const float* wr = w + (size_t)co * K;
+    for (int k = 0; k < K; ++k) {
+      const float wv = wr[k];
+#pragma unroll
+      for (int pi = 0; pi < CI_PIX; ++pi) acc[pi] += wv * patch[pi][k];
+    }
+#pragma unroll
+    for (int pi = 0; pi < CI_PIX; ++pi)
+      if (m0 + pi < M) out[(size_t)(m0 + pi) * Cout + co] = acc[pi];
+  }
+}
+
+constexpr int CO_MAXN = 8;
+// h NHWC fp32 (already GroupNorm+SiLU'd), w [Cout][3][3][Cin] fp32 -> out NCHW fp32; one wave per output pixel
+__global__ void __launch_bounds__(256) conv_out_kernel(const float* h, const float* w, const float* bias, float* out, int B,
+                                                       int H, int W, int Cin, int Cout) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int M = B * H * W;
+  if (m >= M) return;
+  const int b = m / (H * W), rem = m - b * H * W, y = rem / W, x = rem - y * W;
+  float acc[CO_MAXN];
+#pragma unroll
+  for (int n = 0; n < CO_MAXN; ++n) acc[n] = 0.f;
+  const int K = 9 * Cin;
+  for (int tap = 0; tap < 9; ++tap) {
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const int iy = y + ky - 1, ix = x + kx - 1;
+    if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
+    const float* src = h + ((size_t)(b * H + iy) * W + ix) * Cin;
+    for (int c = lane * 4; c < Cin; c += 256) {
+      const f32x4 xv = *(const f32x4*)(src + c);
+#pragma unroll
+      for (int n = 0; n < CO_MAXN; ++n) {
+        if (n < Cout) {
+          const f32x4 wv = *(const f32x4*)(w + (size_t)n * K + tap * Cin + c);
+          acc[n] += wv[0] * xv[0] + wv[1] * xv[1] + wv[2] * xv[2] + wv[3] * xv[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < CO_MAXN; ++n) {
+    if (n < Cout) {
+      float v = acc[n];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) out[(((size_t)b * Cout + n) * H + y) * W + x] = v + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
+// ---- packing -------------------------------------------------------------------------------------------
+__global__ void pack_conv_kernel(const float* w, f16* dst, int O, int I, int KH, int KW) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)O * I * KH * KW;
+  if (idx >= total) return;
+  // dst index: ((o*KH + ky)*KW + kx)*I + i
+  const int i = (int)(idx % I);
+  int64_t r = idx / I;
+  const int kx = (int)(r % KW); r /= KW;
+  const int ky = (int)(r % KH);
+  const int o = (int)(r / KH);
+  dst[idx] = (f16)w[(((int64_t)o * I + i) * KH + ky) * KW + kx];
+}
+__global__ void pack_conv_f32_kernel(const float* w, float* dst, int O, int I, int KH, int KW) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)O * I * KH * KW;
+  if (idx >= total) return;
+  const int i = (int)(idx % I);
+  int64_t r = idx / I;
+  const int kx = (int)(r % KW); r /= KW;
+  const int ky = (int)(r % KH);
+  const int o = (int)(r / KH);
+  dst[idx] = w[(((int64_t)o * I + i) * KH + ky) * KW + kx];
+}
+__global__ void pack_rows_kernel(const float* w, f16* dst, int rows, int cols, int dst_row0, int dst_ld) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)rows * cols) return;
+  const int r = (int)(idx / cols), c = (int)(idx - (int64_t)r * cols);
+  dst[(int64_t)(dst_row0 + r) * dst_ld + c] = (f16)w[idx];
+}
+// GEGLU: dst row 64q + j  <- value row 32q + j (j < 32) | gate row N/2 + 32q + (j - 32)
+__global__ void pack_geglu_kernel(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * K) return;
+  const int r = (int)(idx / K), c = (int)(idx - (int64_t)r * K);
+  const int q = r >> 6, j = r & 63;
+  const int src = (j < 32) ? (32 * q + j) : (N / 2 + 32 * q + (j - 32));
+  wdst[idx] = (f16)w[(int64_t)src * K + c];
+  if (c == 0 && bias) bdst[r] = bias[src];
+}
+
+}  // namespace
+
+// frequency table of the sinusoidal embedding, computed on the host exactly like util.py:160-162
+//   freqs = exp(-log(max_period) * arange(half, float32) / half)   (fp32 ops)
+static float* g_freqs[16] = {nullptr};
+static int g_freqs_half[16] = {0};
+static int get_freqs(int half, const float** out) {
+  int dev = 0;
+  SDMI_HIP_OK(hipGetDevice(&dev));
+  SDMI_CHECK(dev < 16, "device index");
+  if (g_freqs[dev] == nullptr || g_freqs_half[dev] != half) {
+    if (g_freqs[dev]) (void)hipFree(g_freqs[dev]);
+    std::vector<float> f(half);
+    const float nl = (float)(-9.210340371976184);   // -math.log(10000), cast to the tensor dtype (fp32) as torch does
+    for (int i = 0; i < half; ++i) f[i] = expf(nl * (float)i / (float)half);
+    SDMI_HIP_OK(hipMalloc((void**)&g_freqs[dev], half * sizeof(float)));
+    SDMI_HIP_OK(hipMemcpy(g_freqs[dev], f.data(), half * sizeof(float), hipMemcpyHostToDevice));
+    g_freqs_half[dev] = half;
+  }
+  *out = g_freqs[dev];
+  return 0;
+}
+
+int launch_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, hipStream_t s) {
+  SDMI_CHECK((t_i64 != nullptr) != (t_f32 != nullptr), "exactly one of int64 / fp32 timesteps");
+  const float* freqs = nullptr;
+  if (get_freqs(dim / 2, &freqs)) return -1;
+  const int total = B * (dim / 2);
+  hipLaunchKernelGGL(temb_kernel, dim3(cdiv(total, 128)), dim3(128), 0, s, t_i64, t_f32, freqs, out, B, dim);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_small_linear(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out, int B,
+                        int N, int K, int silu_in, hipStream_t s) {
+  SDMI_CHECK(B >= 1 && B <= SL_MAXB, "small_linear: batch must be 1..8");
+  SDMI_CHECK(K % 4 == 0 && ld_in % 4 == 0, "small_linear: K % 4");
+  ProfScope ps("small_linear_f32", 2.0 * B * (double)N * K, (double)N * K * 4.0, s);
+  hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, ld_in, w, bias, out, ld_out, B, N, K,
+                     silu_in);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_in(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
+                   hipStream_t s) {
+  SDMI_CHECK(Cin * 9 <= CI_MAXK, "conv_in: in_channels <= 16");
+  ProfScope ps("conv_in_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
+  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv(B * H * W, CI_PIX)), dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, Cout);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_conv_out(const float* h, const float* w, const float* bias, float* out, int B, int H, int W, int Cin, int Cout,
+                    hipStream_t s) {
+  SDMI_CHECK(Cout <= CO_MAXN && Cin % 4 == 0, "conv_out: out_channels <= 8, Cin % 4 == 0");
+  ProfScope ps("conv_out_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
+  hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_pack_conv_weight(const float* w, f16* dst, int O, int I, int KH, int KW, hipStream_t s) {
+  const int64_t total = (int64_t)O * I * KH * KW;
+  hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, KH, KW);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+int launch_pack_conv_out(const float* w, float* dst, int O, int I, hipStream_t s) {
+  const int64_t total = (int64_t)O * I * 9;
+  hipLaunchKernelGGL(pack_conv_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, 3, 3);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0, int dst_ld, hipStream_t s) {
+  const int64_t total = (int64_t)rows * cols;
+  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, rows, cols,
+                     dst_row0, dst_ld);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+int launch_pack_geglu(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K, hipStream_t s) {
+  SDMI_CHECK(N % 64 == 0, "GEGLU pack: N % 64");
+  const int64_t total = (int64_t)N * K;
+  hipLaunchKernelGGL(pack_geglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, bias, wdst, bdst, N, K);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+}  // namespace sdmi

@@ -1,0 +1,631 @@
+// UNet executor: the static launch graph of UNetModel.forward
+// (ldm/modules/diffusionmodules/openaimodel.py:710-742) over the gfx950 kernels of this library.
+//
+// Data layout in HBM (per forward call, B = CFG batch):
+//   * residual stream and skip stack: fp32 NHWC [B*H*W][C] (rounded nowhere; see DESIGN.md "precision")
+//   * MFMA A operands (normalised activations, q/k/v^T, GEGLU output): fp16, written once by the producing
+//     kernel and read once by the consuming GEMM
+//   * weights: fp16 [N][K] (K = ky,kx,cin), packed once at load; norm/bias/time-embedding parameters fp32
+//   * workspace = [persist | scratch]: every layer output lives in `persist` until the call ends (skip stack),
+//     `scratch` is rewound after each layer so temporaries stay in the 256 MB Infinity Cache.
+#include "unet.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace sdmi {
+
+// ------------------------------------------------------------------------------------------------------
+// construction: mirror of UNetModel.__init__ (openaimodel.py:443-692) for the SD-v1 family
+// ------------------------------------------------------------------------------------------------------
+static bool in_list(const int* v, int n, int x) {
+  for (int i = 0; i < n; ++i)
+    if (v[i] == x) return true;
+  return false;
+}
+
+void UNet::expect(const std::string& key, std::vector<int64_t> shape, WKind kind, void** dst, int row0, int ld,
+                  void** dst2) {
+  WeightSlot s;
+  s.key = key; s.shape = std::move(shape); s.kind = kind; s.dst = dst; s.row0 = row0; s.ld = ld; s.dst2 = dst2;
+  slot_index_[key] = (int)slots_.size();
+  slots_.push_back(std::move(s));
+}
+
+int UNet::build(const sdmi_unet_cfg& c) {
+  cfg_ = c;
+  SDMI_CHECK(c.n_levels >= 1 && c.n_levels <= 8 && c.n_attention_resolutions >= 0 && c.n_attention_resolutions <= 8,
+             "bad level / attention_resolutions count");
+  SDMI_CHECK(c.model_channels % 64 == 0, "model_channels must be a multiple of 64 on this path");
+  SDMI_CHECK(c.context_dim % 64 == 0, "context_dim must be a multiple of 64 on this path");
+  SDMI_CHECK(c.num_heads >= 1 && c.transformer_depth >= 1, "num_heads / transformer_depth");
+  const int mc = c.model_channels;
+  te_ = 4 * mc;
+
+  auto add_res = [&](const std::string& p, int cin, int cout) {
+    Layer L; L.kind = L_RES; L.prefix = p; L.cin = cin; L.cout = cout;
+    L.emb_off = emb_total_; emb_total_ += cout;
+    return L;
+  };
+  auto add_attn = [&](const std::string& p, int ch) {
+    Layer L; L.kind = L_ATTN; L.prefix = p; L.cin = ch; L.cout = ch; L.heads = c.num_heads; L.dh = ch / c.num_heads;
+    L.attn_index = n_attn_++;
+    return L;
+  };
+
+  {
+    Layer L; L.kind = L_CONV_IN; L.prefix = "input_blocks.0.0"; L.cin = c.in_channels; L.cout = mc;
+    input_blocks_.push_back({L});
+  }
+  std::vector<int> chans{mc};
+  int ch = mc, ds = 1;
+  for (int level = 0; level < c.n_levels; ++level) {
+    const int mult = c.channel_mult[level];
+    for (int r = 0; r < c.num_res_blocks; ++r) {
+      const int n = (int)input_blocks_.size();
+      std::vector<Layer> blk;
+      blk.push_back(add_res("input_blocks." + std::to_string(n) + ".0", ch, mult * mc));
+      ch = mult * mc;
+      if (in_list(c.attention_resolutions, c.n_attention_resolutions, ds))
+        blk.push_back(add_attn("input_blocks." + std::to_string(n) + ".1", ch));
+      input_blocks_.push_back(blk);
+      chans.push_back(ch);
+    }
+    if (level != c.n_levels - 1) {
+      const int n = (int)input_blocks_.size();
+      Layer L; L.kind = L_DOWN; L.prefix = "input_blocks." + std::to_string(n) + ".0"; L.cin = ch; L.cout = ch;
+      input_blocks_.push_back({L});
+      chans.push_back(ch);
+      ds *= 2;
+    }
+  }
+  middle_.push_back(add_res("middle_block.0", ch, ch));
+  middle_.push_back(add_attn("middle_block.1", ch));
+  middle_.push_back(add_res("middle_block.2", ch, ch));
+  for (int level = c.n_levels - 1; level >= 0; --level) {
+    const int mult = c.channel_mult[level];
+    for (int i = 0; i <= c.num_res_blocks; ++i) {
+      const int ich = chans.back(); chans.pop_back();
+      const int n = (int)output_blocks_.size();
+      std::vector<Layer> blk;
+      blk.push_back(add_res("output_blocks." + std::to_string(n) + ".0", ch + ich, mc * mult));
+      ch = mc * mult;
+      if (in_list(c.attention_resolutions, c.n_attention_resolutions, ds))
+        blk.push_back(add_attn("output_blocks." + std::to_string(n) + "." + std::to_string(blk.size()), ch));
+      if (level && i == c.num_res_blocks) {
+        Layer L; L.kind = L_UP; L.prefix = "output_blocks." + std::to_string(n) + "." + std::to_string(blk.size());
+        L.cin = ch; L.cout = ch;
+        blk.push_back(L);
+        ds /= 2;
+      }
+      output_blocks_.push_back(blk);
+    }
+  }
+
+  // ---- expected state_dict entries and where each one is packed to -------------------
+  const int64_t TE = te_;
+  expect("time_embed.0.weight", {TE, mc}, W_F32, (void**)&te_w0_);
+  expect("time_embed.0.bias", {TE}, W_F32, (void**)&te_b0_);
+  expect("time_embed.2.weight", {TE, TE}, W_F32, (void**)&te_w2_);
+  expect("time_embed.2.bias", {TE}, W_F32, (void**)&te_b2_);
+  auto visit = [&](Layer& L) {
+    const std::string& p = L.prefix;
+    const int64_t ci = L.cin, co = L.cout;
+    switch (L.kind) {
+      case L_CONV_IN:
+        expect(p + ".weight", {co, ci, 3, 3}, W_F32, (void**)&L.w32[0]);
+        expect(p + ".bias", {co}, W_F32, (void**)&L.f32[0]);
+        break;
+      case L_RES:
+        expect(p + ".in_layers.0.weight", {ci}, W_F32, (void**)&L.f32[0]);
+        expect(p + ".in_layers.0.bias", {ci}, W_F32, (void**)&L.f32[1]);
+        expect(p + ".in_layers.2.weight", {co, ci, 3, 3}, W_CONV, (void**)&L.w16[0]);
+        expect(p + ".in_layers.2.bias", {co}, W_F32, (void**)&L.f32[2]);
+        expect(p + ".emb_layers.1.weight", {co, TE}, W_F32_ROWS, (void**)&emb_w_, L.emb_off, te_);
+        expect(p + ".emb_layers.1.bias", {co}, W_F32_ROWS, (void**)&emb_b_, L.emb_off, 1);
+        expect(p + ".out_layers.0.weight", {co}, W_F32, (void**)&L.f32[3]);
+        expect(p + ".out_layers.0.bias", {co}, W_F32, (void**)&L.f32[4]);
+        expect(p + ".out_layers.3.weight", {co, co, 3, 3}, W_CONV, (void**)&L.w16[1]);
+        expect(p + ".out_layers.3.bias", {co}, W_F32, (void**)&L.f32[5]);
+        if (ci != co) {
+          expect(p + ".skip_connection.weight", {co, ci, 1, 1}, W_CONV, (void**)&L.w16[2]);
+          expect(p + ".skip_connection.bias", {co}, W_F32, (void**)&L.f32[6]);
+        }
+        break;
+      case L_ATTN: {
+        const int64_t C = ci, CD = cfg_.context_dim;
+        expect(p + ".norm.weight", {C}, W_F32, (void**)&L.f32[0]);
+        expect(p + ".norm.bias", {C}, W_F32, (void**)&L.f32[1]);
+        expect(p + ".proj_in.weight", {C, C, 1, 1}, W_CONV, (void**)&L.w16[0]);
+        expect(p + ".proj_in.bias", {C}, W_F32, (void**)&L.f32[2]);
+        expect(p + ".proj_out.weight", {C, C, 1, 1}, W_CONV, (void**)&L.w16[1]);
+        expect(p + ".proj_out.bias", {C}, W_F32, (void**)&L.f32[3]);
+        L.tb.resize(cfg_.transformer_depth);
+        for (int d = 0; d < cfg_.transformer_depth; ++d) {
+          TBlock& T = L.tb[d];
+          const std::string t = p + ".transformer_blocks." + std::to_string(d);
+          expect(t + ".attn1.to_q.weight", {C, C}, W_ROWS16, (void**)&T.wqkv, 0, (int)C);
+          expect(t + ".attn1.to_k.weight", {C, C}, W_ROWS16, (void**)&T.wqkv, (int)C, (int)C);
+          expect(t + ".attn1.to_v.weight", {C, C}, W_ROWS16, (void**)&T.wqkv, 2 * (int)C, (int)C);
+          expect(t + ".attn1.to_out.0.weight", {C, C}, W_ROWS16, (void**)&T.wo1, 0, (int)C);
+          expect(t + ".attn1.to_out.0.bias", {C}, W_F32, (void**)&T.bo1);
+          expect(t + ".attn2.to_q.weight", {C, C}, W_ROWS16, (void**)&T.wq2, 0, (int)C);
+          expect(t + ".attn2.to_k.weight", {C, CD}, W_ROWS16, (void**)&T.wkv2, 0, (int)CD);
+          expect(t + ".attn2.to_v.weight", {C, CD}, W_ROWS16, (void**)&T.wkv2, (int)C, (int)CD);
+          expect(t + ".attn2.to_out.0.weight", {C, C}, W_ROWS16, (void**)&T.wo2, 0, (int)C);
+          expect(t + ".attn2.to_out.0.bias", {C}, W_F32, (void**)&T.bo2);
+          expect(t + ".ff.net.0.proj.weight", {8 * C, C}, W_GEGLU_W, (void**)&T.wgg);
+          expect(t + ".ff.net.0.proj.bias", {8 * C}, W_GEGLU_B, (void**)&T.bgg);
+          expect(t + ".ff.net.2.weight", {C, 4 * C}, W_ROWS16, (void**)&T.wff2, 0, 4 * (int)C);
+          expect(t + ".ff.net.2.bias", {C}, W_F32, (void**)&T.bff2);
+          expect(t + ".norm1.weight", {C}, W_F32, (void**)&T.ln[0]);
+          expect(t + ".norm1.bias", {C}, W_F32, (void**)&T.ln[1]);
+          expect(t + ".norm2.weight", {C}, W_F32, (void**)&T.ln[2]);
+          expect(t + ".norm2.bias", {C}, W_F32, (void**)&T.ln[3]);
+          expect(t + ".norm3.weight", {C}, W_F32, (void**)&T.ln[4]);
+          expect(t + ".norm3.bias", {C}, W_F32, (void**)&T.ln[5]);
+        }
+        break;
+      }
+      case L_DOWN:
+        expect(p + ".op.weight", {co, ci, 3, 3}, W_CONV, (void**)&L.w16[0]);
+        expect(p + ".op.bias", {co}, W_F32, (void**)&L.f32[0]);
+        break;
+      case L_UP:
+        expect(p + ".conv.weight", {co, ci, 3, 3}, W_CONV, (void**)&L.w16[0]);
+        expect(p + ".conv.bias", {co}, W_F32, (void**)&L.f32[0]);
+        break;
+    }
+  };
+  // NOTE: slots hold pointers into the Layer objects, so the containers must not reallocate after this point.
+  for (auto& blk : input_blocks_) for (auto& L : blk) visit(L);
+  for (auto& L : middle_) visit(L);
+  for (auto& blk : output_blocks_) for (auto& L : blk) visit(L);
+  expect("out.0.weight", {mc}, W_F32, (void**)&out_gamma_);
+  expect("out.0.bias", {mc}, W_F32, (void**)&out_beta_);
+  expect("out.2.weight", {c.out_channels, mc, 3, 3}, W_CONV_OUT, (void**)&out_w_);
+  expect("out.2.bias", {c.out_channels}, W_F32, (void**)&out_b_);
+  return 0;
+}
+
+UNet::~UNet() {
+  for (void* p : owned_) (void)hipFree(p);
+}
+
+int UNet::dev_alloc(void** dst, size_t bytes) {
+  if (*dst) return 0;
+  SDMI_HIP_OK(hipMalloc(dst, bytes));
+  owned_.push_back(*dst);
+  return 0;
+}
+
+int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, int ndim, hipStream_t stream) {
+  auto it = slot_index_.find(key);
+  if (it == slot_index_.end()) return fail(std::string("unexpected weight key: ") + key);
+  WeightSlot& s = slots_[it->second];
+  SDMI_CHECK((int)s.shape.size() == ndim, std::string("rank mismatch for ") + key);
+  int64_t numel = 1;
+  for (int i = 0; i < ndim; ++i) {
+    SDMI_CHECK(shape[i] == s.shape[i], std::string("shape mismatch for ") + key);
+    numel *= shape[i];
+  }
+  // host pointer? stage it on the device first
+  const float* dptr = ptr;
+  float* staged = nullptr;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, ptr);
+  bool on_device = (e == hipSuccess) && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+  if (e != hipSuccess) (void)hipGetLastError();
+  if (!on_device) {
+    SDMI_HIP_OK(hipMalloc((void**)&staged, numel * sizeof(float)));
+    SDMI_HIP_OK(hipMemcpyAsync(staged, ptr, numel * sizeof(float), hipMemcpyHostToDevice, stream));
+    dptr = staged;
+  }
+  int rc = 0;
+  switch (s.kind) {
+    case W_F32:
+      rc = dev_alloc(s.dst, numel * sizeof(float));
+      if (!rc) SDMI_HIP_OK(hipMemcpyAsync(*s.dst, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice, stream));
+      break;
+    case W_F32_ROWS: {   // rows of a concatenated fp32 matrix (the 22 emb_layers)
+      rc = dev_alloc(s.dst, (size_t)emb_total_ * s.ld * sizeof(float));
+      if (!rc)
+        SDMI_HIP_OK(hipMemcpyAsync((float*)*s.dst + (size_t)s.row0 * s.ld, dptr, numel * sizeof(float),
+                                   hipMemcpyDeviceToDevice, stream));
+      break;
+    }
+    case W_CONV:
+      rc = dev_alloc(s.dst, numel * sizeof(f16));
+      if (!rc) rc = launch_pack_conv_weight(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], (int)shape[2], (int)shape[3], stream);
+      break;
+    case W_CONV_OUT:
+      rc = dev_alloc(s.dst, numel * sizeof(float));
+      if (!rc) rc = launch_pack_conv_out(dptr, (float*)*s.dst, (int)shape[0], (int)shape[1], stream);
+      break;
+    case W_ROWS16: {     // rows [row0, row0+rows) of an fp16 [*, ld] matrix (q|k|v and k|v concatenations)
+      // total rows of the destination: qkv -> 3C, kv -> 2C, others -> rows; allocate by the largest user
+      const int rows = (int)shape[0];
+      size_t total_rows = rows;
+      const std::string k(key);
+      if (k.find(".attn1.to_") != std::string::npos && k.find("to_out") == std::string::npos) total_rows = 3 * (size_t)rows;
+      if (k.find(".attn2.to_k") != std::string::npos || k.find(".attn2.to_v") != std::string::npos) total_rows = 2 * (size_t)rows;
+      rc = dev_alloc(s.dst, total_rows * s.ld * sizeof(f16));
+      if (!rc) rc = launch_pack_rows(dptr, (f16*)*s.dst, rows, (int)shape[1], s.row0, s.ld, stream);
+      break;
+    }
+    case W_GEGLU_W: {
+      // weight and bias arrive separately; the weight packer does not need the bias (and vice versa)
+      rc = dev_alloc(s.dst, numel * sizeof(f16));
+      if (!rc) rc = launch_pack_geglu(dptr, nullptr, (f16*)*s.dst, nullptr, (int)shape[0], (int)shape[1], stream);
+      break;
+    }
+    case W_GEGLU_B: {
+      rc = dev_alloc(s.dst, numel * sizeof(float));
+      // permute the bias with the same 32-row interleave: reuse the packer with K = 1 on a [N][1] "matrix"
+      if (!rc) {
+        f16* tmp = nullptr;
+        SDMI_HIP_OK(hipMalloc((void**)&tmp, numel * sizeof(f16)));
+        rc = launch_pack_geglu(dptr, dptr, tmp, (float*)*s.dst, (int)shape[0], 1, stream);
+        SDMI_HIP_OK(hipStreamSynchronize(stream));
+        (void)hipFree(tmp);
+      }
+      break;
+    }
+  }
+  if (staged) {
+    SDMI_HIP_OK(hipStreamSynchronize(stream));
+    (void)hipFree(staged);
+  }
+  if (rc) return rc;
+  s.set = true;
+  finalized_ = false;
+  return 0;
+}
+
+int UNet::finalize() {
+  for (auto& s : slots_)
+    if (!s.set) return fail("weight not set: " + s.key);
+  if (!zero_) {
+    SDMI_HIP_OK(hipMalloc((void**)&zero_, 4096));
+    owned_.push_back(zero_);
+    SDMI_HIP_OK(hipMemset(zero_, 0, 4096));
+  }
+  finalized_ = true;
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------------------
+struct Arena {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0; bool dry = false; bool overflow = false;
+  void* alloc(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    peak = std::max(peak, off);
+    if (dry) return (void*)(uintptr_t)(a + 4096);   // fake non-null address; never dereferenced
+    if (off > cap) { overflow = true; return base; }
+    return base + a;
+  }
+};
+
+struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
+
+struct Fwd {
+  UNet* u; hipStream_t s; bool dry; int B, Lctx;
+  Arena persist, scratch;
+  float* gn_partial = nullptr;
+  float* emb_all = nullptr;     // [B][emb_total]
+  const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
+  int rc = 0;
+
+  template <class T> T* P(size_t n) { return (T*)persist.alloc(n * sizeof(T)); }
+  template <class T> T* S(size_t n) { return (T*)scratch.alloc(n * sizeof(T)); }
+  void ok(int r) { if (r && !rc) rc = r; }
+
+  void gemm(IGemmParams& p) {
+    p.zero_page = u->zero_;
+    if (!dry && !rc) ok(launch_igemm(p, IGemmTune(), s));
+  }
+  // dense [M][K] x W[N][K]^T
+  IGemmParams dense(const f16* a, int M, int K, const f16* w, int N, int rows_per_batch) {
+    IGemmParams p;
+    p.a0 = a; p.c0 = K; p.lda0 = K;
+    p.B = M / rows_per_batch; p.Hin = p.Hout = rows_per_batch; p.Win = p.Wout = 1;
+    p.ksize = 1; p.w = w; p.M = M; p.N = N; p.K = K; p.splitk = 0;
+    return p;
+  }
+  IGemmParams conv3(const f16* a, int C, int Hin, int Win, int Hout, int Wout, int stride, int up, const f16* w, int N) {
+    IGemmParams p;
+    p.a0 = a; p.c0 = C; p.lda0 = C;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+    p.ksize = 3; p.stride = stride; p.up = up; p.w = w; p.M = B * Hout * Wout; p.N = N; p.K = 9 * C; p.splitk = 0;
+    return p;
+  }
+  void groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
+                 float* o32, f16* raw) {
+    GroupNormParams g;
+    g.x0 = x0.p; g.c0 = x0.C;
+    if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
+    g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
+    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.partial = gn_partial;
+    if (!dry && !rc) ok(launch_groupnorm(g, s));
+  }
+
+  Act res_block(Layer& L, const Act& x0, const Act* x1) {
+    const int H = x0.H, W = x0.W, M = B * H * W;
+    const int Cin = x0.C + (x1 ? x1->C : 0), Cout = L.cout;
+    if (Cin != L.cin) { ok(fail("res block channel mismatch at " + L.prefix)); }
+    const size_t mark = scratch.off;
+    f16* a = S<f16>((size_t)M * Cin);
+    f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
+    groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw);
+    float* h = S<float>((size_t)M * Cout);
+    {
+      IGemmParams p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
+      p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = u->emb_total_;
+      p.out_f32 = h; p.ldo = Cout;
+      gemm(p);
+    }
+    f16* a2 = S<f16>((size_t)M * Cout);
+    Act hact; hact.p = h; hact.C = Cout; hact.H = H; hact.W = W;
+    groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
+    Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
+    const float* residual = x0.p;
+    if (Cin != Cout) {
+      IGemmParams p = dense(raw, M, Cin, L.w16[2], Cout, H * W);
+      p.bias = L.f32[6]; p.out_f32 = out.p; p.ldo = Cout;
+      gemm(p);
+      residual = out.p;
+    } else if (x1) {
+      ok(fail("identity skip with a concatenated input at " + L.prefix));
+    }
+    {
+      IGemmParams p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
+      p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
+      gemm(p);
+    }
+    scratch.off = mark;
+    return out;
+  }
+
+  // K / V^T of the cross-attention for one transformer block (depends on the context only)
+  void context_kv(Layer& L, int d) {
+    TBlock& T = L.tb[d];
+    const int C = L.cin, Lp = (int)round_up(Lctx, 8);
+    IGemmParams p = dense(ctx16, B * Lctx, u->cfg_.context_dim, T.wkv2, 2 * C, Lctx);
+    p.mode = EPI_HEADS; p.seg_dst[0] = T.ck; p.seg_dst[1] = T.cvt; p.seg_kind[0] = 0; p.seg_kind[1] = 1;
+    p.heads = L.heads; p.dh = L.dh; p.ntok = Lctx; p.ntok_pad = Lp; p.segC = C; p.splitk = 1;
+    if (!dry && !rc && Lp != Lctx) {
+      hipError_t e = hipMemsetAsync(T.cvt, 0, (size_t)B * C * Lp * sizeof(f16), s);
+      if (e != hipSuccess) ok(fail(std::string("hipMemsetAsync: ") + hipGetErrorString(e)));
+    }
+    gemm(p);
+  }
+
+  Act attn_block(Layer& L, const Act& x) {
+    const int H = x.H, W = x.W, N = H * W, M = B * N, C = L.cin;
+    const int Np = (int)round_up(N, 8), Lp = (int)round_up(Lctx, 8);
+    const float scale = 1.0f / sqrtf((float)L.dh);
+    const size_t mark = scratch.off;
+    f16* xn = S<f16>((size_t)M * C);
+    groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr);
+    float* t = S<float>((size_t)M * C);
+    {
+      IGemmParams p = dense(xn, M, C, L.w16[0], C, N);
+      p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
+      gemm(p);
+    }
+    f16* ln = S<f16>((size_t)M * C);
+    f16* q = S<f16>((size_t)M * C);
+    f16* k = S<f16>((size_t)M * C);
+    f16* vt = S<f16>((size_t)B * C * Np);
+    f16* ao = S<f16>((size_t)M * C);
+    f16* gg = S<f16>((size_t)M * 4 * C);
+    for (int d = 0; d < (int)L.tb.size(); ++d) {
+      TBlock& T = L.tb[d];
+      // x = attn1(norm1(x)) + x                                   attention.py:212
+      if (!dry && !rc) ok(launch_layernorm(t, T.ln[0], T.ln[1], ln, M, C, 1e-5f, s));
+      {
+        IGemmParams p = dense(ln, M, C, T.wqkv, 3 * C, N);
+        p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_dst[1] = k; p.seg_dst[2] = vt;
+        p.seg_kind[0] = 0; p.seg_kind[1] = 0; p.seg_kind[2] = 1;
+        p.heads = L.heads; p.dh = L.dh; p.ntok = N; p.ntok_pad = Np; p.segC = C; p.splitk = 1;
+        if (!dry && !rc && Np != N) {
+          hipError_t e = hipMemsetAsync(vt, 0, (size_t)B * C * Np * sizeof(f16), s);
+          if (e != hipSuccess) ok(fail(std::string("hipMemsetAsync: ") + hipGetErrorString(e)));
+        }
+        gemm(p);
+      }
+      attention(q, k, vt, ao, L, N, N, Np, scale);
+      {
+        IGemmParams p = dense(ao, M, C, T.wo1, C, N);
+        p.bias = T.bo1; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
+        gemm(p);
+      }
+      // x = attn2(norm2(x), context) + x                           attention.py:213
+      if (!dry && !rc) ok(launch_layernorm(t, T.ln[2], T.ln[3], ln, M, C, 1e-5f, s));
+      {
+        IGemmParams p = dense(ln, M, C, T.wq2, C, N);
+        p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_kind[0] = 0;
+        p.heads = L.heads; p.dh = L.dh; p.ntok = N; p.ntok_pad = Np; p.segC = C; p.splitk = 1;
+        gemm(p);
+      }
+      if (ctx16) context_kv(L, d);
+      attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);
+      {
+        IGemmParams p = dense(ao, M, C, T.wo2, C, N);
+        p.bias = T.bo2; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
+        gemm(p);
+      }
+      // x = ff(norm3(x)) + x                                       attention.py:214
+      if (!dry && !rc) ok(launch_layernorm(t, T.ln[4], T.ln[5], ln, M, C, 1e-5f, s));
+      {
+        IGemmParams p = dense(ln, M, C, T.wgg, 8 * C, N);
+        p.mode = EPI_GEGLU; p.bias = T.bgg; p.out_f16 = gg; p.ldo = 4 * C; p.splitk = 1;
+        gemm(p);
+      }
+      {
+        IGemmParams p = dense(gg, M, 4 * C, T.wff2, C, N);
+        p.bias = T.bff2; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
+        gemm(p);
+      }
+    }
+    if (!dry && !rc) ok(launch_cast_f16(t, ln, (int64_t)M * C, s));
+    Act out; out.p = P<float>((size_t)M * C); out.C = C; out.H = H; out.W = W;
+    {
+      IGemmParams p = dense(ln, M, C, L.w16[1], C, N);
+      p.bias = L.f32[3]; p.residual = x.p; p.ldr = C; p.out_f32 = out.p; p.ldo = C;
+      gemm(p);
+    }
+    scratch.off = mark;
+    return out;
+  }
+
+  void attention(const f16* q, const f16* k, const f16* vt, f16* out, Layer& L, int nq, int nkv, int nkv_pad, float scale) {
+    AttnParams a;
+    a.q = q; a.k = k; a.vt = vt; a.out = out; a.BH = B * L.heads; a.heads = L.heads; a.nq = nq; a.nkv = nkv;
+    a.nkv_pad = nkv_pad; a.d = L.dh; a.scale = scale;
+    if (!dry && !rc) ok(launch_attention(a, s));
+  }
+
+  Act resample(Layer& L, const Act& x, bool up) {
+    const int Hin = x.H, Win = x.W, C = x.C;
+    const int Hout = up ? 2 * Hin : (Hin - 1) / 2 + 1, Wout = up ? 2 * Win : (Win - 1) / 2 + 1;
+    const size_t mark = scratch.off;
+    f16* x16 = S<f16>((size_t)B * Hin * Win * C);
+    if (!dry && !rc) ok(launch_cast_f16(x.p, x16, (int64_t)B * Hin * Win * C, s));
+    Act out; out.p = P<float>((size_t)B * Hout * Wout * C); out.C = L.cout; out.H = Hout; out.W = Wout;
+    IGemmParams p = conv3(x16, C, Hin, Win, Hout, Wout, up ? 1 : 2, up ? 1 : 0, L.w16[0], L.cout);
+    p.bias = L.f32[0]; p.out_f32 = out.p; p.ldo = L.cout;
+    gemm(p);
+    scratch.off = mark;
+    return out;
+  }
+
+  Act run_layer(Layer& L, const Act& x, const Act* skip) {
+    switch (L.kind) {
+      case L_RES: return res_block(L, x, skip);
+      case L_ATTN: return attn_block(L, x);
+      case L_DOWN: return resample(L, x, false);
+      case L_UP: return resample(L, x, true);
+      default: ok(fail("unexpected layer kind")); return x;
+    }
+  }
+};
+
+int UNet::ensure_ctx_cache(int B, int Lctx) {
+  if (ctx_B_ == B && ctx_L_ == Lctx) return 0;
+  const int Lp = (int)round_up(Lctx, 8);
+  auto each = [&](Layer& L) -> int {
+    if (L.kind != L_ATTN) return 0;
+    for (auto& T : L.tb) {
+      if (T.ck) { (void)hipFree(T.ck); T.ck = nullptr; }
+      if (T.cvt) { (void)hipFree(T.cvt); T.cvt = nullptr; }
+      SDMI_HIP_OK(hipMalloc((void**)&T.ck, (size_t)B * Lctx * L.cin * sizeof(f16)));
+      SDMI_HIP_OK(hipMalloc((void**)&T.cvt, (size_t)B * L.cin * Lp * sizeof(f16)));
+    }
+    return 0;
+  };
+  for (auto& blk : input_blocks_) for (auto& L : blk) if (each(L)) return -1;
+  for (auto& L : middle_) if (each(L)) return -1;
+  for (auto& blk : output_blocks_) for (auto& L : blk) if (each(L)) return -1;
+  ctx_B_ = B; ctx_L_ = Lctx; ctx_valid_ = false;
+  return 0;
+}
+
+int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx, float* eps_out, int B, int H,
+              int W, int Lctx, void* workspace, int64_t ws_bytes, hipStream_t stream, bool dry, bool ctx_only,
+              int64_t* bytes_needed) {
+  SDMI_CHECK(dry || finalized_, "sdmi_unet_finalize() has not succeeded yet");
+  SDMI_CHECK(B >= 1 && B <= 8, "batch (CFG rows) must be 1..8 per call");
+  SDMI_CHECK(H >= 1 && W >= 1 && Lctx >= 1, "bad shape");
+  const int down = 1 << (cfg_.n_levels - 1);
+  SDMI_CHECK(H % down == 0 && W % down == 0, "H and W must be divisible by 2^(levels-1) (the UNet's skip concat requires it)");
+
+  Fwd f;
+  f.u = this; f.s = stream; f.dry = dry; f.B = B; f.Lctx = Lctx;
+  // first pass (always dry) sizes the two arenas; the persist arena sits in front of the scratch arena
+  int64_t persist_bytes = 0, scratch_bytes = 0;
+  for (int pass = (dry ? 0 : 0); pass < 2; ++pass) {
+    const bool d = (pass == 0) ? true : false;
+    if (pass == 1 && dry) break;
+    f.dry = d; f.rc = 0;
+    f.persist = Arena(); f.scratch = Arena();
+    f.persist.dry = f.scratch.dry = d;
+    if (!d) {
+      SDMI_CHECK(persist_bytes + scratch_bytes <= ws_bytes, "workspace too small: need " +
+                 std::to_string(persist_bytes + scratch_bytes) + " bytes, got " + std::to_string(ws_bytes));
+      SDMI_CHECK(workspace != nullptr, "workspace is NULL");
+      f.persist.base = (char*)workspace; f.persist.cap = (size_t)persist_bytes;
+      f.scratch.base = (char*)workspace + persist_bytes; f.scratch.cap = (size_t)scratch_bytes;
+      if (ensure_ctx_cache(B, Lctx)) return -1;
+    }
+    const int mc = cfg_.model_channels;
+    f.gn_partial = f.P<float>(gn_partial_floats(B, H * W));
+    f16* ctx16 = f.P<f16>((size_t)B * Lctx * cfg_.context_dim);
+    const bool have_ctx = (ctx != nullptr) || d;
+    if (have_ctx) {
+      if (!d) { int r = launch_cast_f16(ctx, ctx16, (int64_t)B * Lctx * cfg_.context_dim, stream); if (r) return r; }
+      f.ctx16 = ctx16;
+    } else {
+      SDMI_CHECK(ctx_valid_, "ctx == NULL but no cached context for this (B, Lctx); call sdmi_unet_cache_context first");
+      f.ctx16 = nullptr;
+    }
+    if (ctx_only) {
+      auto each = [&](Layer& L) { if (L.kind == L_ATTN) for (int dd = 0; dd < (int)L.tb.size(); ++dd) f.context_kv(L, dd); };
+      for (auto& blk : input_blocks_) for (auto& L : blk) each(L);
+      for (auto& L : middle_) each(L);
+      for (auto& blk : output_blocks_) for (auto& L : blk) each(L);
+    } else {
+      // ---- time embedding (util.py:151-171, openaimodel.py:506-511,723-724) and all emb_layers at once ----
+      float* temb = f.P<float>((size_t)B * mc);
+      float* e1 = f.P<float>((size_t)B * te_);
+      float* emb = f.P<float>((size_t)B * te_);
+      f.emb_all = f.P<float>((size_t)B * emb_total_);
+      if (!d) {
+        int r = launch_timestep_embedding(t_i64, t_f32, temb, B, mc, stream);
+        if (!r) r = launch_small_linear(temb, mc, te_w0_, te_b0_, e1, te_, B, te_, mc, 0, stream);
+        if (!r) r = launch_small_linear(e1, te_, te_w2_, te_b2_, emb, te_, B, te_, te_, 1, stream);
+        if (!r) r = launch_small_linear(emb, te_, emb_w_, emb_b_, f.emb_all, emb_total_, B, emb_total_, te_, 1, stream);
+        if (r) return r;
+      }
+      // ---- input blocks ----
+      std::vector<Act> hs;
+      Act h;
+      {
+        Layer& L = input_blocks_[0][0];
+        h.p = f.P<float>((size_t)B * H * W * mc); h.C = mc; h.H = H; h.W = W;
+        if (!d) { int r = launch_conv_in(x, L.w32[0], L.f32[0], h.p, B, cfg_.in_channels, H, W, mc, stream); if (r) return r; }
+        hs.push_back(h);
+      }
+      for (size_t bi = 1; bi < input_blocks_.size(); ++bi) {
+        for (auto& L : input_blocks_[bi]) h = f.run_layer(L, h, nullptr);
+        hs.push_back(h);
+      }
+      for (auto& L : middle_) h = f.run_layer(L, h, nullptr);
+      for (auto& blk : output_blocks_) {
+        Act skip = hs.back(); hs.pop_back();
+        SDMI_CHECK(skip.H == h.H && skip.W == h.W, "skip/h spatial mismatch");
+        bool first = true;
+        for (auto& L : blk) { h = f.run_layer(L, h, first ? &skip : nullptr); first = false; }
+      }
+      // ---- output head: GN -> SiLU -> conv3x3 (fp32) ----
+      float* hn = f.S<float>((size_t)B * H * W * mc);
+      f.groupnorm(h, nullptr, out_gamma_, out_beta_, 1e-5f, 1, nullptr, hn, nullptr);
+      if (!d && !f.rc) { int r = launch_conv_out(hn, out_w_, out_b_, eps_out, B, H, W, mc, cfg_.out_channels, stream); if (r) return r; }
+    }
+    if (f.rc) return f.rc;
+    if (d) { persist_bytes = (int64_t)f.persist.peak + 256; scratch_bytes = (int64_t)f.scratch.peak + 256; }
+    else {
+      SDMI_CHECK(!f.persist.overflow && !f.scratch.overflow, "internal: arena overflow");
+      if (have_ctx) ctx_valid_ = true;
+    }
+  }
+  if (bytes_needed) *bytes_needed = persist_bytes + scratch_bytes;
+  return 0;
+}
+
+}  // namespace sdmi

@@ -1,0 +1,35 @@
+"""Seeded random weights in the SD-v1 UNet architecture (there is no checkpoint in the build environment).
+
+Used by bench.py, the launcher and smoke runs.  Default-initialised reference weights give eps == 0
+(`zero_module`, openaimodel.py:229-231,685; attention.py:244-248), so every tensor is drawn here.
+Throughput is value independent; the values only need to keep activations O(1).
+"""
+import math
+
+import torch
+
+
+@torch.no_grad()
+def randomize_(unet, seed=0):
+    """In-place init of a UNetModelHIP (or anything with the same parameter names)."""
+    dev = next(unet.parameters()).device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in unet.named_parameters():
+        if name.endswith('.weight') and p.dim() >= 2:
+            fan_in = p[0].numel()
+            zero_init = name.endswith('out_layers.3.weight') or name.endswith('proj_out.weight') or name == 'out.2.weight'
+            std = (0.5 if zero_init else 0.577) / math.sqrt(fan_in)
+            p.copy_(torch.randn(p.shape, generator=g, device=dev) * std)
+        elif name.endswith('.weight'):      # norm gamma
+            p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev))
+        else:                               # biases / norm beta
+            p.copy_(0.02 * torch.randn(p.shape, generator=g, device=dev))
+    if hasattr(unet, 'mark_dirty'):
+        unet.mark_dirty()
+    return unet
+
+
+SD_V1_UNET_KWARGS = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320,
+                         attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
+                         use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,
+                         legacy=False)   # configs/stable-diffusion/v1-inference.yaml:29-44

@@ -1,0 +1,229 @@
+"""`UNetModelHIP` -- drop-in for `ldm.modules.diffusionmodules.openaimodel.UNetModel` on MI355X.
+
+Plugged in through the reference's own plugin mechanism (`instantiate_from_config`, ldm/util.py:78-93):
+a copy of configs/stable-diffusion/v1-inference.yaml with
+
+    unet_config:
+      target: stable_diffusion_amd.unet.UNetModelHIP
+
+Same constructor keywords (openaimodel.py:443-470), same parameter names (so
+`model.load_state_dict(sd, strict=False)` at scripts/txt2img.py:56 fills it), same call
+`diffusion_model(x, t, context=cc)` (ldm/models/diffusion/ddpm.py:1410).  The arithmetic runs in
+libsdmi.so (hand-written gfx950 kernels); this class only owns the parameters, packs them into the
+library on first use and hands raw device pointers across the C ABI.
+"""
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib
+
+
+def make_cfg(in_channels, out_channels, model_channels, num_res_blocks, channel_mult, attention_resolutions,
+             num_heads, transformer_depth, context_dim):
+    cfg = _lib.UNetCfg()
+    cfg.in_channels, cfg.out_channels, cfg.model_channels = in_channels, out_channels, model_channels
+    cfg.num_res_blocks = num_res_blocks
+    channel_mult = list(channel_mult)
+    attention_resolutions = list(attention_resolutions)
+    if len(channel_mult) > 8 or len(attention_resolutions) > 8:
+        raise ValueError('at most 8 levels / attention resolutions')
+    cfg.n_levels = len(channel_mult)
+    for i, m in enumerate(channel_mult):
+        cfg.channel_mult[i] = int(m)
+    cfg.n_attention_resolutions = len(attention_resolutions)
+    for i, a in enumerate(attention_resolutions):
+        cfg.attention_resolutions[i] = int(a)
+    cfg.num_heads, cfg.transformer_depth, cfg.context_dim = num_heads, transformer_depth, int(context_dim)
+    return cfg
+
+
+class _Handle:
+    """Owns one sdmi_unet*."""
+
+    def __init__(self, cfg):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        _lib.check(self.lib.sdmi_unet_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+
+    def weight_specs(self):
+        n = self.lib.sdmi_unet_num_weights(self.h)
+        out = []
+        buf = C.create_string_buffer(256)
+        shape = (C.c_int64 * 4)()
+        nd = C.c_int()
+        for i in range(n):
+            _lib.check(self.lib.sdmi_unet_weight_info(self.h, i, buf, 256, shape, C.byref(nd)))
+            out.append((buf.value.decode(), tuple(shape[j] for j in range(nd.value))))
+        return out
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.sdmi_unet_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class _Node(nn.Module):
+    """Name-only container so parameter paths equal the reference's (e.g. input_blocks.1.0.in_layers.0.weight)."""
+
+
+class UNetModelHIP(nn.Module):
+    def __init__(self, image_size, in_channels, model_channels, out_channels, num_res_blocks, attention_resolutions,
+                 dropout=0, channel_mult=(1, 2, 4, 8), conv_resample=True, dims=2, num_classes=None,
+                 use_checkpoint=False, use_fp16=False, num_heads=-1, num_head_channels=-1, num_heads_upsample=-1,
+                 use_scale_shift_norm=False, resblock_updown=False, use_new_attention_order=False,
+                 use_spatial_transformer=False, transformer_depth=1, context_dim=None, n_embed=None, legacy=True):
+        super().__init__()
+        # the SD-v1 family only (configs/stable-diffusion/v1-inference.yaml:29-44); anything else is refused loudly
+        unsupported = []
+        if not use_spatial_transformer or context_dim is None: unsupported.append('use_spatial_transformer=True with context_dim')
+        if legacy: unsupported.append('legacy=False')
+        if num_heads == -1 or num_head_channels != -1: unsupported.append('num_heads (not num_head_channels)')
+        if num_heads_upsample not in (-1, num_heads): unsupported.append('num_heads_upsample == num_heads')
+        if dims != 2 or not conv_resample or resblock_updown or use_scale_shift_norm: unsupported.append('dims=2, conv_resample, plain ResBlocks')
+        if num_classes is not None or n_embed is not None: unsupported.append('no class conditioning / codebook head')
+        if dropout != 0: unsupported.append('dropout=0')
+        if unsupported:
+            raise NotImplementedError('UNetModelHIP supports the SD-v1 UNet family only; needs: ' + '; '.join(unsupported))
+        if isinstance(context_dim, (list, tuple)) or type(context_dim).__name__ == 'ListConfig':
+            context_dim = list(context_dim)[0]
+        self.image_size = image_size
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.num_res_blocks = num_res_blocks
+        self.attention_resolutions = list(attention_resolutions)
+        self.channel_mult = list(channel_mult)
+        self.num_heads, self.transformer_depth, self.context_dim = num_heads, transformer_depth, int(context_dim)
+        self.use_checkpoint = use_checkpoint      # accepted, meaningless at inference (util.py:102-128)
+        self.dtype = torch.float32
+        self._cfg = make_cfg(in_channels, out_channels, model_channels, num_res_blocks, self.channel_mult,
+                             self.attention_resolutions, num_heads, transformer_depth, self.context_dim)
+        self._handle = _Handle(self._cfg)
+        self._specs = self._handle.weight_specs()
+        for key, shape in self._specs:
+            *path, leaf = key.split('.')
+            node = self
+            for name in path:
+                if name not in node._modules:
+                    node.add_module(name, _Node())
+                node = node._modules[name]
+            node.register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
+        self._packed_sig = None
+        self._sentinels = None
+        self._ws = None
+        self._ctx_ref = None
+        self._ctx_ver = None
+        self._ctx_shape = None
+        self._pinned = None
+
+    # ---- weights -> library ---------------------------------------------------------------------------
+    # Re-pack whenever the parameters may have changed: device moves / dtype casts (_apply), load_state_dict,
+    # or an explicit mark_dirty() after in-place edits.  A cheap per-call check of a few sentinel tensors catches
+    # the common in-place cases without walking all 686 parameters on the hot path.
+    def _apply(self, fn, *a, **k):
+        self._packed_sig = None
+        return super()._apply(fn, *a, **k)
+
+    def load_state_dict(self, *a, **k):
+        self._packed_sig = None
+        return super().load_state_dict(*a, **k)
+
+    def mark_dirty(self):
+        self._packed_sig = None
+
+    def _signature(self):
+        if getattr(self, '_sentinels', None) is None:
+            ps = dict(self.named_parameters())
+            keys = [self._specs[0][0], self._specs[len(self._specs) // 2][0], self._specs[-1][0]]
+            self._sentinels = [ps[k] for k in keys]
+        return tuple((p.data_ptr(), p._version) for p in self._sentinels)
+
+    def pack(self):
+        """Hand every parameter to the library (repacked to fp16 [N][K] there). Called lazily by forward()."""
+        lib = self._handle.lib
+        stream = _lib.stream_ptr()
+        ps = dict(self.named_parameters())
+        for key, shape in self._specs:
+            p = ps[key].detach()
+            if not p.is_cuda:
+                raise RuntimeError('UNetModelHIP parameters must live on the GPU (call model.cuda() first); '
+                                   'there is no CPU implementation of this path')
+            p = p.float().contiguous()
+            shp = (C.c_int64 * len(shape))(*shape)
+            _lib.check(lib.sdmi_unet_set_weight(self._handle.h, key.encode(), p.data_ptr(), shp, len(shape), stream))
+        torch.cuda.current_stream().synchronize()
+        _lib.check(lib.sdmi_unet_finalize(self._handle.h))
+        self._sentinels = None
+        self._packed_sig = self._signature()
+        self._ctx_ref = None
+
+    def _workspace(self, B, H, W, L, device):
+        key = (B, H, W, L, str(device))
+        if self._ws is None or self._ws[0] != key:
+            need = self._handle.lib.sdmi_unet_workspace_bytes(self._handle.h, B, H, W, L)
+            if need <= 0:
+                _lib.check(-1)
+            self._ws = (key, torch.empty(int(need), dtype=torch.uint8, device=device))
+        return self._ws[1]
+
+    # ---- context pinning (used by the HIP samplers) ------------------------------------------------------------
+    def pin_context(self, context):
+        """Compute the cross-attention K/V of every SpatialTransformer for `context` once (attention.py:174-176
+        depend on the context only) and reuse them for every forward() until unpin_context().  The caller promises
+        to keep passing a context with the same contents (the sampler loop does: c_in is constant over the steps)."""
+        if not context.is_cuda:
+            raise RuntimeError('UNetModelHIP runs on an MI355X device tensor only (no CPU fallback)')
+        if self._packed_sig is None or self._packed_sig != self._signature():
+            self.pack()
+        B, L, D = context.shape
+        assert D == self.context_dim
+        down = 2 ** (len(self.channel_mult) - 1)
+        ws = self._workspace(B, down, down, L, context.device)
+        ctx32 = context.detach().float().contiguous()
+        _lib.check(self._handle.lib.sdmi_unet_cache_context(self._handle.h, ctx32.data_ptr(), B, L, ws.data_ptr(),
+                                                            ws.numel(), _lib.stream_ptr()))
+        self._pinned = (B, L)
+        self._ctx_ref = None
+
+    def unpin_context(self):
+        self._pinned = None
+
+    # ---- UNetModel.forward (openaimodel.py:710-742) ----------------------------------------------------------
+    @torch.no_grad()
+    def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        assert y is None, 'must specify y if and only if the model is class-conditional'
+        if not x.is_cuda:
+            raise RuntimeError('UNetModelHIP runs on an MI355X device tensor only (no CPU fallback)')
+        if context is None or timesteps is None:
+            raise ValueError('timesteps and context are required')
+        if self._packed_sig is None or self._packed_sig != self._signature():
+            self.pack()
+        B, Cin, H, W = x.shape
+        assert Cin == self.in_channels
+        x32 = x.detach().float().contiguous()
+        if timesteps.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8):
+            t_i64, t_f32 = timesteps.detach().to(torch.int64).contiguous(), None
+        else:
+            t_i64, t_f32 = None, timesteps.detach().float().contiguous()
+        assert (t_i64 if t_i64 is not None else t_f32).shape == (B,)
+        assert context.dim() == 3 and context.shape[0] == B and context.shape[2] == self.context_dim
+        L = context.shape[1]
+        ws = self._workspace(B, H, W, L, x.device)
+        # cross-attention K/V depend on the context only: skip their recomputation while the caller keeps
+        # passing the very same (unmodified) tensor object
+        reuse = (self._pinned == (B, L)) or \
+            ((self._ctx_ref is context) and (self._ctx_ver == context._version) and self._ctx_shape == (B, L))
+        ctx32 = None
+        if not reuse:
+            ctx32 = context.detach().float().contiguous()
+        out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        _lib.check(self._handle.lib.sdmi_unet_forward(
+            self._handle.h, x32.data_ptr(), _lib.ptr(t_i64), _lib.ptr(t_f32), _lib.ptr(ctx32), out.data_ptr(),
+            B, H, W, L, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
+        if self._pinned is None:
+            self._ctx_ref, self._ctx_ver, self._ctx_shape = context, context._version, (B, L)
+        return out

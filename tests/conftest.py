@@ -1,0 +1,34 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def pytest_collection_modifyitems(config, items):
+    """GPU tests must not silently pass on a GPU-less host: they are skipped there unless selected with -m gpu,
+    in which case a missing GPU is an error (the product path has no fallback)."""
+    import torch
+    if torch.cuda.is_available():
+        return
+    for item in items:
+        if 'gpu' in item.keywords:
+            item.add_marker(pytest.mark.skip(reason='no GPU on this host'))
+
+
+@pytest.fixture(scope='session')
+def lib():
+    from stable_diffusion_amd import _lib
+    return _lib.load()
+
+
+@pytest.fixture(scope='session')
+def golden_dir():
+    return os.path.join(ROOT, 'tests', 'golden')

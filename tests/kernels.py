@@ -1,0 +1,145 @@
+"""torch-tensor wrappers around the kernel-level C-ABI entry points (sdmi_k_*), shared by the GPU tests."""
+import ctypes as C
+
+import torch
+
+from stable_diffusion_amd import _lib
+
+
+def _s():
+    return _lib.stream_ptr()
+
+
+def pack_conv_weight(w):
+    """[O,I,KH,KW] fp32 cuda -> fp16 [O, KH*KW*I]"""
+    O, I, KH, KW = w.shape
+    dst = torch.empty((O, KH * KW * I), dtype=torch.float16, device=w.device)
+    _lib.check(_lib.load().sdmi_k_pack_conv_weight(w.contiguous().data_ptr(), dst.data_ptr(), O, I, KH, KW, _s()))
+    return dst
+
+
+def pack_geglu(w, b):
+    N, K = w.shape
+    wd = torch.empty((N, K), dtype=torch.float16, device=w.device)
+    bd = torch.empty((N,), dtype=torch.float32, device=w.device)
+    _lib.check(_lib.load().sdmi_k_pack_geglu(w.contiguous().data_ptr(), b.contiguous().data_ptr(), wd.data_ptr(),
+                                             bd.data_ptr(), N, K, _s()))
+    return wd, bd
+
+
+def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, bias=None, rowvec=None, residual=None,
+          out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None):
+    """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
+    d = _lib.IGemmDesc()
+    d.a0 = a0.data_ptr(); d.c0 = a0.shape[1]; d.lda0 = a0.stride(0)
+    if a1 is not None:
+        d.a1 = a1.data_ptr(); d.c1 = a1.shape[1]; d.lda1 = a1.stride(0)
+    d.B, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.up = B, Hin, Win, Hout, Wout, ksize, stride, up
+    d.w = w.data_ptr(); d.N = N; d.mode = mode
+    d.bias = _lib.ptr(bias)
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0)
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ldr = residual.stride(0)
+    d.out_f32 = _lib.ptr(out_f32); d.out_f16 = _lib.ptr(out_f16)
+    d.ldo = ldo if ldo is not None else (out_f32.stride(0) if out_f32 is not None else
+                                         (out_f16.stride(0) if out_f16 is not None else 0))
+    if heads is not None:
+        for i, (t, kind) in enumerate(heads['segs']):
+            d.seg_dst[i] = t.data_ptr(); d.seg_kind[i] = kind
+        d.heads, d.dh, d.ntok, d.ntok_pad, d.segC = heads['heads'], heads['dh'], heads['ntok'], heads['ntok_pad'], heads['segC']
+    d.splitk, d.tile, d.dma = splitk, tile, dma
+    _lib.check(_lib.load().sdmi_k_igemm(C.byref(d), _s()))
+
+
+def attention(q, k, vt, heads, nkv, scale):
+    """q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> [B, nq, heads*d] fp16"""
+    BH, nq, d = q.shape
+    out = torch.empty((BH // heads, nq, heads * d), dtype=torch.float16, device=q.device)
+    _lib.check(_lib.load().sdmi_k_attention(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), BH, heads, nq,
+                                            nkv, vt.shape[2], d, float(scale), _s()))
+    return out
+
+
+def groupnorm(x0, x1, gamma, beta, eps, silu, want=('f16',)):
+    """x0/x1: fp32 [B, HW, C] -> dict of outputs"""
+    B, HW, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[2]
+    C_ = c0 + c1
+    dev = x0.device
+    o16 = torch.empty((B, HW, C_), dtype=torch.float16, device=dev) if 'f16' in want else None
+    o32 = torch.empty((B, HW, C_), dtype=torch.float32, device=dev) if 'f32' in want else None
+    raw = torch.empty((B, HW, C_), dtype=torch.float16, device=dev) if 'raw' in want else None
+    n = _lib.load().sdmi_k_groupnorm_ws_floats(B, HW)
+    ws = torch.empty((n,), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().sdmi_k_groupnorm(x0.data_ptr(), _lib.ptr(x1), c0, c1, B, HW, gamma.data_ptr(),
+                                            beta.data_ptr(), float(eps), int(silu), _lib.ptr(o16), _lib.ptr(o32),
+                                            _lib.ptr(raw), ws.data_ptr(), n, _s()))
+    return dict(f16=o16, f32=o32, raw=raw)
+
+
+def layernorm(x, gamma, beta, eps=1e-5):
+    M, C_ = x.shape
+    out = torch.empty((M, C_), dtype=torch.float16, device=x.device)
+    _lib.check(_lib.load().sdmi_k_layernorm(x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), out.data_ptr(), M, C_,
+                                            float(eps), _s()))
+    return out
+
+
+def timestep_embedding(t, dim):
+    B = t.shape[0]
+    out = torch.empty((B, dim), dtype=torch.float32, device=t.device)
+    if t.dtype == torch.int64:
+        _lib.check(_lib.load().sdmi_k_timestep_embedding(t.data_ptr(), None, out.data_ptr(), B, dim, _s()))
+    else:
+        _lib.check(_lib.load().sdmi_k_timestep_embedding(None, t.float().contiguous().data_ptr(), out.data_ptr(), B, dim, _s()))
+    return out
+
+
+def small_linear(x, w, b, silu_in):
+    B, K = x.shape
+    N = w.shape[0]
+    out = torch.empty((B, N), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sdmi_k_small_linear(x.data_ptr(), x.stride(0), w.data_ptr(), _lib.ptr(b), out.data_ptr(), N,
+                                               B, N, K, int(silu_in), _s()))
+    return out
+
+
+def conv_in(x, w, b):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, H * W, Cout), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sdmi_k_conv_in(x.data_ptr(), w.data_ptr(), b.data_ptr(), out.data_ptr(), B, Cin, H, W, Cout, _s()))
+    return out
+
+
+def conv_out(h, w, b, B, H, W):
+    """h: fp32 [B, HW, Cin]; w: OIHW fp32"""
+    Cout, Cin = w.shape[0], w.shape[1]
+    wp = torch.empty((Cout, 3, 3, Cin), dtype=torch.float32, device=h.device)
+    _lib.check(_lib.load().sdmi_k_pack_conv_out(w.contiguous().data_ptr(), wp.data_ptr(), Cout, Cin, _s()))
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=h.device)
+    _lib.check(_lib.load().sdmi_k_conv_out(h.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, _s()))
+    return out
+
+
+def sampler_step(eps_model, cfg, scale, x, mode, old, a_t, a_prev, sigma, s1m, noise=None):
+    e_t = torch.empty_like(x); x_prev = torch.empty_like(x); pred = torch.empty_like(x)
+    o = list(old) + [None] * 3
+    _lib.check(_lib.load().sdmi_sampler_step(eps_model.data_ptr(), int(cfg), float(scale), x.data_ptr(), mode,
+                                             _lib.ptr(o[0]), _lib.ptr(o[1]), _lib.ptr(o[2]), float(a_t), float(a_prev),
+                                             float(sigma), float(s1m), _lib.ptr(noise), e_t.data_ptr(),
+                                             x_prev.data_ptr(), pred.data_ptr(), x.numel(), _s()))
+    return e_t, x_prev, pred
+
+
+def report(name, got, ref, tol):
+    """max-abs / rel diagnostics printed for the GPU log; returns the max-abs error."""
+    got = got.float().cpu(); ref = ref.float().cpu()
+    d = (got - ref).abs()
+    mx = d.max().item()
+    idx = int(d.flatten().argmax())
+    print(f'[{name}] max-abs {mx:.3e} (tol {tol:.1e}) ref-absmax {ref.abs().max().item():.3e} rms-err '
+          f'{d.pow(2).mean().sqrt().item():.3e} at flat {idx}: got {got.flatten()[idx].item():.6f} ref '
+          f'{ref.flatten()[idx].item():.6f} nan={bool(torch.isnan(got).any())}', flush=True)
+    return mx

@@ -1,0 +1,56 @@
+"""CPU, world_size 2 over gloo: prompt sharding and the single latent all_gather of the multi-GPU path."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, n_total, q):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from stable_diffusion_amd import dist as sd_dist
+    r, w, _ = sd_dist.init_from_env(backend='gloo')
+    assert (r, w) == (rank, world)
+    mine = sd_dist.shard(list(range(n_total)), r, w)
+    # "latent" of prompt i is a tensor filled with i (seeded by the GLOBAL index, independent of world size)
+    local = torch.stack([torch.full((4, 8, 8), float(i)) for i, _ in mine]) if mine else torch.zeros((0, 4, 8, 8))
+    full = sd_dist.gather_latents(local, n_total, r, w)
+    ok = full.shape == (n_total, 4, 8, 8) and all(float(full[i].mean()) == float(i) for i in range(n_total))
+    mx = sd_dist.max_over_ranks(10.0 + rank, torch.device('cpu'))
+    q.put((rank, bool(ok), mx))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('n_total', [8, 5, 1])
+def test_shard_and_gather_world2(n_total):
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_total, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert all(mx == 11.0 for _, _, mx in res)
+
+
+def test_single_process_passthrough():
+    from stable_diffusion_amd import dist as sd_dist
+    x = torch.randn(3, 4, 8, 8)
+    assert sd_dist.gather_latents(x, 3, 0, 1) is x
+    assert sd_dist.shard(['a', 'b', 'c'], 0, 1) == [(0, 'a'), (1, 'b'), (2, 'c')]
+    assert sd_dist.shard(['a', 'b', 'c'], 1, 2) == [(1, 'b')]

@@ -1,0 +1,300 @@
+"""GPU parity of every gfx950 kernel against fp32 torch restatements of the reference op (through the C ABI).
+
+Operands are fp16-representable, so the reference value is exact up to fp32 accumulation order; tolerances are
+written next to each check."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import kernels as K  # noqa: E402  (tests/ is on sys.path via conftest's rootdir insertion)
+
+DEV = 'cuda'
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def _rand16(shape, g, scale=1.0):
+    return (torch.randn(shape, generator=g) * scale).half()
+
+
+def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
+    B, C, H, W = x.shape
+    return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
+
+
+CONV_CASES = [
+    # name, B, Hin, Win, c0, c1, N, ksize, stride, up
+    ('dense_masked', 2, 10, 10, 320, 0, 328, 1, 1, 0),
+    ('conv3_s1', 2, 12, 12, 64, 0, 128, 3, 1, 0),
+    ('conv3_s2', 2, 12, 12, 128, 0, 64, 3, 2, 0),
+    ('conv3_s2_odd', 1, 7, 9, 64, 0, 64, 3, 2, 0),
+    ('conv3_up', 2, 6, 6, 64, 0, 192, 3, 1, 1),
+    ('conv3_cat', 2, 8, 8, 64, 128, 64, 3, 1, 0),
+    ('conv1_cat', 2, 8, 8, 128, 64, 320, 1, 1, 0),
+    ('tiny_m', 1, 2, 2, 256, 0, 256, 3, 1, 0),
+]
+
+
+def _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up):
+    x = a0.float() if a1 is None else torch.cat([a0.float(), a1.float()], dim=1)
+    C = x.shape[1]
+    x = x.reshape(B, Hin, Win, C).permute(0, 3, 1, 2)
+    if up:
+        x = F.interpolate(x, scale_factor=2, mode='nearest')
+    return F.conv2d(x, w.float(), None, stride=stride, padding=1 if ksize == 3 else 0)
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
+@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('dma', [0, 1])
+def test_igemm_conv(case, tile, dma):
+    name, B, Hin, Win, c0, c1, N, ksize, stride, up = case
+    g = _g(hash(name) % 1000)
+    Cin = c0 + c1
+    a0 = _rand16((B * Hin * Win, c0), g)
+    a1 = _rand16((B * Hin * Win, c1), g) if c1 else None
+    w = _rand16((N, Cin, ksize, ksize), g, 1.0 / math.sqrt(Cin * ksize * ksize))
+    ref = _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up)          # [B,N,Hout,Wout] fp32 (CPU)
+    Hout, Wout = ref.shape[2], ref.shape[3]
+    M = B * Hout * Wout
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref2 = _nhwc(ref) + bias[None] + rowvec.repeat_interleave(Hout * Wout, dim=0) + resid
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    out32 = torch.full((M, N), float('nan'), device=DEV)
+    out16 = torch.full((M, N), float('nan'), device=DEV, dtype=torch.float16)
+    K.igemm(a0.to(DEV), wp, N, B, Hin, Win, Hout, Wout, ksize, stride, up, a1=None if a1 is None else a1.to(DEV),
+            bias=bias.to(DEV), rowvec=rowvec.to(DEV), residual=resid.to(DEV), out_f32=out32, out_f16=out16,
+            tile=tile, dma=dma)
+    torch.cuda.synchronize()
+    # fp32 accumulate of exact products: only summation order differs -> 2e-4 abs on O(1) outputs
+    assert K.report(f'igemm {name} tile{tile} dma{dma} f32', out32, ref2, 2e-4) < 2e-4
+    # fp16 copy: one rounding of |v| <= ~8 -> 2^-11 * 8 = 4e-3
+    assert K.report(f'igemm {name} tile{tile} dma{dma} f16', out16, ref2, 6e-3) < 6e-3
+
+
+@pytest.mark.parametrize('splitk', [0, 2, 5])
+@pytest.mark.parametrize('tile', [0, 2])
+def test_igemm_splitk_inplace_residual(splitk, tile):
+    g = _g(5)
+    B, H, W, C, N = 2, 4, 4, 256, 192
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(9 * C))
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(B * H * W, N, generator=g)
+    ref = _nhwc(_conv_ref(a, None, w, B, H, W, 3, 1, 0)) + bias[None] + resid
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    out = resid.clone().to(DEV)              # in place: out is also the residual (ResBlock skip path)
+    K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV), residual=out, out_f32=out, splitk=splitk, tile=tile)
+    torch.cuda.synchronize()
+    assert K.report(f'igemm splitk{splitk} tile{tile}', out, ref, 2e-4) < 2e-4
+
+
+def test_igemm_geglu():
+    """FeedForward/GEGLU, attention.py:37-64: value = first half, gate = second half, exact erf GELU."""
+    g = _g(6)
+    M, Kd, N = 200, 128, 512
+    a = _rand16((M, Kd), g)
+    w = _rand16((N, Kd), g, 1.0 / math.sqrt(Kd))
+    b = torch.randn(N, generator=g) * 0.1
+    y = a.float() @ w.float().t() + b
+    val, gate = y.chunk(2, dim=-1)
+    ref = val * F.gelu(gate)
+    wp, bp = K.pack_geglu(w.float().to(DEV), b.to(DEV))
+    out = torch.full((M, N // 2), float('nan'), device=DEV, dtype=torch.float16)
+    K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1)
+    torch.cuda.synchronize()
+    assert K.report('igemm geglu', out, ref, 4e-3) < 4e-3
+
+
+@pytest.mark.parametrize('ntok,d,heads', [(64, 40, 8), (77, 32, 2), (16, 160, 8), (100, 80, 4)])
+def test_igemm_head_scatter(ntok, d, heads):
+    """'b n (h d) -> (b h) n d' (attention.py:176) for q / k, and the transposed layout for v."""
+    g = _g(7)
+    B = 2
+    C = heads * d
+    Kd = 128
+    M = B * ntok
+    a = _rand16((M, Kd), g)
+    w = _rand16((3 * C, Kd), g, 1.0 / math.sqrt(Kd))
+    y = (a.float() @ w.float().t()).reshape(B, ntok, 3, heads, d)
+    ntp = (ntok + 7) // 8 * 8
+    q = torch.zeros((B * heads, ntok, d), dtype=torch.float16, device=DEV)
+    k = torch.zeros_like(q)
+    vt = torch.zeros((B * heads, d, ntp), dtype=torch.float16, device=DEV)
+    wp = w.to(DEV).contiguous()
+    K.igemm(a.to(DEV), wp, 3 * C, B, ntok, 1, ntok, 1, mode=2,
+            heads=dict(segs=[(q, 0), (k, 0), (vt, 1)], heads=heads, dh=d, ntok=ntok, ntok_pad=ntp, segC=C))
+    torch.cuda.synchronize()
+    qr = y[:, :, 0].permute(0, 2, 1, 3).reshape(B * heads, ntok, d)
+    kr = y[:, :, 1].permute(0, 2, 1, 3).reshape(B * heads, ntok, d)
+    vr = y[:, :, 2].permute(0, 2, 3, 1).reshape(B * heads, d, ntok)
+    assert K.report('heads q', q, qr, 4e-3) < 4e-3
+    assert K.report('heads k', k, kr, 4e-3) < 4e-3
+    assert K.report('heads vt', vt[:, :, :ntok], vr, 4e-3) < 4e-3
+    assert float(vt[:, :, ntok:].abs().max()) == 0.0 if ntp != ntok else True
+
+
+def test_igemm_sd_l0_conv_shape():
+    """The dominant SD-v1 shape: 320->320 3x3 at 64x64, CFG batch 2."""
+    g = _g(8)
+    B, H, W, C, N = 2, 64, 64, 320, 320
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(9 * C))
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    out = torch.empty((B * H * W, N), device=DEV)
+    K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, out_f32=out)
+    torch.cuda.synchronize()
+    x = a.float().to(DEV).reshape(B, H, W, C).permute(0, 3, 1, 2)
+    ref = _nhwc(F.conv2d(x, w.float().to(DEV), None, padding=1))
+    assert K.report('igemm L0 conv', out, ref, 3e-4) < 3e-4
+
+
+ATTN_CASES = [
+    # d, heads, nq, nkv
+    (40, 8, 256, 256), (40, 8, 4096, 4096), (80, 8, 1024, 1024), (160, 8, 256, 256), (160, 8, 64, 64),
+    (40, 8, 256, 77), (80, 8, 64, 77), (160, 8, 64, 77), (32, 2, 16, 16), (64, 2, 4, 4), (128, 2, 100, 77),
+    (40, 2, 200, 130), (64, 2, 96, 96),
+]
+
+
+@pytest.mark.parametrize('d,heads,nq,nkv', ATTN_CASES)
+def test_attention(d, heads, nq, nkv):
+    """CrossAttention core, attention.py:178-192: softmax(q k^T * d^-0.5) v, heads merged 'b n (h d)'."""
+    g = _g(d + nq + nkv)
+    B = 2 if nq < 4096 else 1
+    BH = B * heads
+    q = _rand16((BH, nq, d), g)
+    k = _rand16((BH, nkv, d), g)
+    v = _rand16((BH, nkv, d), g)
+    # a few large scores so the online-softmax rescale path is exercised (guide rule 26)
+    q[0, 0] *= 6.0
+    k[0, nkv - 1] *= 6.0
+    scale = d ** -0.5
+    sim = torch.bmm(q.float(), k.float().transpose(1, 2)) * scale
+    ref = torch.bmm(sim.softmax(-1), v.float())
+    ref = ref.reshape(B, heads, nq, d).permute(0, 2, 1, 3).reshape(B, nq, heads * d)
+    nkp = (nkv + 7) // 8 * 8
+    vt = torch.zeros((BH, d, nkp), dtype=torch.float16)
+    vt[:, :, :nkv] = v.transpose(1, 2)
+    out = K.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, nkv, scale)
+    torch.cuda.synchronize()
+    # P is rounded to fp16 before PV (rel 2^-11) and the output is stored as fp16: 3e-3 abs on |v| ~ N(0,1)
+    assert K.report(f'attention d{d} nq{nq} nkv{nkv}', out, ref, 3e-3) < 3e-3
+
+
+@pytest.mark.parametrize('c0,c1,HW,silu,eps', [(320, 0, 64 * 64, 1, 1e-5), (1280, 640, 16 * 16, 1, 1e-5),
+                                               (64, 0, 4, 0, 1e-6), (640, 320, 100, 1, 1e-5), (2560, 0, 64, 1, 1e-5)])
+def test_groupnorm(c0, c1, HW, silu, eps):
+    """GroupNorm32 + SiLU (util.py:199-216, openaimodel.py:201-203) over the channel concat of two sources."""
+    g = _g(c0 + HW)
+    B = 2
+    C = c0 + c1
+    x0 = torch.randn(B, HW, c0, generator=g) * 1.5 + 0.3
+    x1 = torch.randn(B, HW, c1, generator=g) * 0.7 - 0.2 if c1 else None
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=2)
+    ref = F.group_norm(x.permute(0, 2, 1).reshape(B, C, HW, 1), 32, gamma, beta, eps)
+    if silu:
+        ref = F.silu(ref)
+    ref = ref.reshape(B, C, HW).permute(0, 2, 1)
+    o = K.groupnorm(x0.to(DEV), None if x1 is None else x1.to(DEV), gamma.to(DEV), beta.to(DEV), eps, silu,
+                    want=('f16', 'f32', 'raw'))
+    torch.cuda.synchronize()
+    assert K.report('groupnorm f32', o['f32'], ref, 2e-5) < 2e-5
+    assert K.report('groupnorm f16', o['f16'], ref, 4e-3) < 4e-3
+    assert K.report('groupnorm raw', o['raw'], x, 4e-3) < 4e-3
+
+
+@pytest.mark.parametrize('M,C', [(8192, 320), (512, 1280), (7, 64), (100, 640)])
+def test_layernorm(M, C):
+    g = _g(M + C)
+    x = torch.randn(M, C, generator=g) * 2 + 0.5
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    out = K.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    torch.cuda.synchronize()
+    assert K.report('layernorm', out, ref, 4e-3) < 4e-3
+
+
+def test_time_embedding_path():
+    """timestep_embedding (util.py:151-171) + time_embed MLP + emb_layers (openaimodel.py:506-511,218-224), fp32."""
+    from oracle.unet_ref import timestep_embedding as ref_temb
+    g = _g(11)
+    t = torch.tensor([981, 481, 1, 0, 999], dtype=torch.int64)
+    ref = ref_temb(t, 320)
+    out = K.timestep_embedding(t.to(DEV), 320)
+    torch.cuda.synchronize()
+    assert K.report('timestep_embedding', out, ref, 2e-4) < 2e-4     # arg up to 999 rad: fp32 range reduction
+    outf = K.timestep_embedding(t.float().to(DEV), 320)
+    assert K.report('timestep_embedding(float t)', outf, ref, 2e-4) < 2e-4
+    w = torch.randn(1280, 320, generator=g) / math.sqrt(320)
+    b = torch.randn(1280, generator=g) * 0.1
+    x = torch.randn(5, 320, generator=g)
+    for silu in (0, 1):
+        refl = F.linear(F.silu(x) if silu else x, w, b)
+        outl = K.small_linear(x.to(DEV), w.to(DEV), b.to(DEV), silu)
+        assert K.report(f'small_linear silu{silu}', outl, refl, 2e-5) < 2e-5
+
+
+def test_conv_in_out():
+    g = _g(12)
+    B, H, W = 2, 9, 12
+    x = torch.randn(B, 4, H, W, generator=g)
+    w = torch.randn(320, 4, 3, 3, generator=g) / 6
+    b = torch.randn(320, generator=g) * 0.1
+    ref = _nhwc(F.conv2d(x, w, b, padding=1)).reshape(B, H * W, 320)
+    out = K.conv_in(x.to(DEV), w.to(DEV), b.to(DEV))
+    assert K.report('conv_in', out, ref, 2e-5) < 2e-5
+    h = torch.randn(B, 320, H, W, generator=g)
+    w2 = torch.randn(4, 320, 3, 3, generator=g) / math.sqrt(2880)
+    b2 = torch.randn(4, generator=g) * 0.1
+    ref2 = F.conv2d(h, w2, b2, padding=1)
+    out2 = K.conv_out(_nhwc(h).reshape(B, H * W, 320).to(DEV), w2.to(DEV), b2.to(DEV), B, H, W)
+    assert K.report('conv_out', out2, ref2, 2e-5) < 2e-5
+
+
+@pytest.mark.parametrize('mode', [0, 1, 2, 3, 4])
+@pytest.mark.parametrize('cfg', [0, 1])
+def test_sampler_step_bit_exact(mode, cfg):
+    """CFG combine + PLMS/DDIM update (plms.py:178-236): bit-identical to the reference's fp32 torch expression."""
+    g = _g(13 + mode)
+    n = (2, 4, 16, 16)
+    x = torch.randn(n, generator=g)
+    eps = torch.randn((4,) + n[1:], generator=g) if cfg else torch.randn(n, generator=g)
+    old = [torch.randn(n, generator=g) for _ in range(3)]
+    a_t, a_prev, sigma = 0.4321, 0.5678, (0.1 if mode == 0 else 0.0)
+    s1m = float(torch.tensor(1.0 - a_t).sqrt())
+    noise = torch.randn(n, generator=g) if sigma else None
+    scale = 7.5
+    if cfg:
+        eu, ec = eps.chunk(2)
+        e_t = eu + scale * (ec - eu)
+    else:
+        e_t = eps
+    if mode == 0: ep = e_t
+    elif mode == 1: ep = (3 * e_t - old[0]) / 2
+    elif mode == 2: ep = (23 * e_t - 16 * old[0] + 5 * old[1]) / 12
+    elif mode == 3: ep = (55 * e_t - 59 * old[0] + 37 * old[1] - 9 * old[2]) / 24
+    else: ep = (old[0] + e_t) / 2
+    b = n[0]
+    at = torch.full((b, 1, 1, 1), a_t); ap = torch.full((b, 1, 1, 1), a_prev)
+    sg = torch.full((b, 1, 1, 1), sigma); sm = torch.full((b, 1, 1, 1), s1m)
+    pred = (x - sm * ep) / at.sqrt()
+    dir_xt = (1. - ap - sg ** 2).sqrt() * ep
+    xp = ap.sqrt() * pred + dir_xt + (sg * noise if noise is not None else 0.)
+    e_o, x_o, p_o = K.sampler_step(eps.to(DEV), cfg, scale, x.to(DEV), mode, [o.to(DEV) for o in old], a_t, a_prev, sigma,
+                                   s1m, None if noise is None else noise.to(DEV))
+    torch.cuda.synchronize()
+    assert torch.equal(e_o.cpu(), e_t), 'post-CFG eps not bit-exact'
+    assert torch.equal(p_o.cpu(), pred), 'pred_x0 not bit-exact'
+    assert torch.equal(x_o.cpu(), xp), 'x_prev not bit-exact'

@@ -1,0 +1,84 @@
+"""CPU: the oracle restatement (oracle/) against the committed reference goldens (tests/golden/), which were produced
+by running the reference modules themselves (oracle/make_golden.py).  This is what pins the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import samplers_ref, unet_ref
+from oracle.plan import SD_V1, SMALL40, TINY, build_plan
+from oracle.weights import make_inputs, make_state_dict, param_specs
+
+CFGS = {'tiny': TINY, 'small40': SMALL40, 'sdv1': SD_V1}
+
+
+@pytest.mark.parametrize('case', ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8'])
+def test_oracle_unet_matches_reference_golden(case, golden_dir):
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg = CFGS[case.split('_')[0]]
+    sd = make_state_dict(cfg, int(z['weight_seed']))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
+                            ctx_len=int(z['ctx_len']))
+    eps = unet_ref.unet_forward(sd, cfg, x, t, ctx)
+    ref = torch.from_numpy(z['eps'])
+    assert eps.shape == ref.shape
+    assert float(ref.abs().max()) > 0.5          # not the trivial all-zero output of default-initialised weights
+    assert (eps - ref).abs().max().item() < 2e-5
+
+
+def test_sd_v1_inventory():
+    """686 state-dict tensors / 859,520,964 parameters, 22 ResBlocks, 16 SpatialTransformers."""
+    specs = param_specs(SD_V1)
+    assert len(specs) == 686
+    n = 0
+    for _, shape, _ in specs:
+        k = 1
+        for s in shape:
+            k *= s
+        n += k
+    assert n == 859520964
+    layers = list(build_plan(SD_V1).all_layers())
+    assert sum(L.kind == 'res' for L in layers) == 22 and sum(L.kind == 'attn' for L in layers) == 16
+    assert [L.d_head for L in layers if L.kind == 'attn'][:3] == [40, 40, 80]
+
+
+def test_schedule_constants(golden_dir):
+    """alphas_cumprod golden values and the S=30 -> 31 steps quirk of make_ddim_timesteps."""
+    G = np.load(os.path.join(golden_dir, 'samplers.npz'))
+    betas, ac = samplers_ref.make_alphas_cumprod()
+    assert np.array_equal(ac, G['alphas_cumprod']) and np.array_equal(betas, G['betas'])
+    assert abs(ac[0] - 0.99915) < 1e-6 and abs(ac[1] - 0.998296) < 1e-6 and abs(ac[981] - 0.0057755) < 1e-7
+    ts = samplers_ref.make_ddim_timesteps(50)
+    assert ts[0] == 1 and ts[-1] == 981 and len(ts) == 50
+    assert len(samplers_ref.make_ddim_timesteps(30)) == 31
+    tabs = samplers_ref.make_sampling_tables(ac, ts)
+    assert tabs['alphas_prev'][0] == ac[0] and tabs['alphas'][0] == ac[1]
+
+
+def _stub(x, t, c):
+    return torch.tanh(0.7 * x + 0.001 * t.float()[:, None, None, None]) * 0.9 \
+        + 0.05 * c.mean(dim=(1, 2))[:, None, None, None]
+
+
+def test_oracle_samplers_match_reference_golden(golden_dir):
+    G = np.load(os.path.join(golden_dir, 'samplers.npz'))
+    ac = G['alphas_cumprod']
+    x_T, c, uc = (torch.from_numpy(G[k]) for k in ('x_T', 'c', 'uc'))
+    for S in (50, 10):
+        calls = []
+
+        def f(x, t, cc):
+            calls.append(int(t[0]))
+            return _stub(x, t, cc)
+        out = samplers_ref.plms_sample(f, ac, S, x_T, c, 7.5, uc)
+        assert len(calls) == S + 1 and calls[-1] == 1
+        assert (out - torch.from_numpy(G[f'plms_{S}'])).abs().max().item() < 1e-6
+        out = samplers_ref.ddim_sample(_stub, ac, S, x_T, c, 7.5, uc)
+        assert (out - torch.from_numpy(G[f'ddim_{S}'])).abs().max().item() < 1e-6
+    out = samplers_ref.plms_sample(_stub, ac, 10, x_T, c)
+    assert (out - torch.from_numpy(G['plms_10_nocfg'])).abs().max().item() < 1e-6
+    z = samplers_ref.ddim_stochastic_encode(ac, 50, torch.from_numpy(G['x0']), 37, torch.from_numpy(G['noise']))
+    assert (z - torch.from_numpy(G['img2img_z'])).abs().max().item() < 1e-6
+    out = samplers_ref.ddim_decode(_stub, ac, 50, z, c, 37, 5.0, uc)
+    assert (out - torch.from_numpy(G['img2img_out'])).abs().max().item() < 1e-6

@@ -1,0 +1,120 @@
+"""Whole-UNet eps parity on the GPU: UNetModelHIP (through the C ABI) vs the committed reference goldens.
+
+The goldens are outputs of the *reference* `UNetModel` (fp32, CPU) produced by oracle/make_golden.py; weights and
+inputs are regenerated here from the same seeds (oracle.weights), so nothing under /root/reference is needed.
+Bar (BASELINE.json north_star): max-abs <= 1e-3 after upcast."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.plan import SD_V1, SMALL40, TINY  # noqa: E402
+from oracle.weights import make_inputs, make_state_dict  # noqa: E402
+
+TOL = 1e-3
+CFGS = {'tiny': TINY, 'small40': SMALL40, 'sdv1': SD_V1}
+_models = {}
+
+
+def _model(cfg_name, wseed):
+    key = (cfg_name, wseed)
+    if key not in _models:
+        _models.clear()
+        torch.cuda.empty_cache()
+        from stable_diffusion_amd import UNetModelHIP
+        cfg = CFGS[cfg_name]
+        sd = make_state_dict(cfg, wseed)
+        kw = cfg.ref_kwargs()
+        kw['use_checkpoint'] = True
+        m = UNetModelHIP(**kw)
+        missing = m.load_state_dict(sd, strict=True)      # same keys / shapes as the reference state_dict
+        m = m.cuda().eval()
+        _models[key] = (m, sd)
+    return _models[key]
+
+
+CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64']
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_unet_eps_matches_reference_golden(case, golden_dir):
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg_name = case.split('_')[0]
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, int(z['weight_seed']))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
+                            ctx_len=int(z['ctx_len']))
+    assert torch.equal(t, torch.from_numpy(z['t']))
+    eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(z['eps'])
+    err = (eps.float().cpu() - ref).abs()
+    print(f'[unet {case}] HIP-vs-reference(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e} '
+          f'|eps|max {ref.abs().max():.3f} nan={bool(torch.isnan(eps).any())}', flush=True)
+    assert eps.shape == ref.shape and eps.dtype == torch.float32
+    assert float(err.max()) <= TOL
+
+
+@pytest.mark.parametrize('case', ['tiny_16x16', 'sdv1_16x16'])
+def test_noise_floor_report(case, golden_dir):
+    """Informational (SURVEY.md 7 'hard parts' iii): the error of stock fp16 autocast (PyTorch-ROCm) on the same
+    inputs, next to the HIP path's -- the 1e-3 bar is tighter than what autocast itself achieves."""
+    from oracle import unet_ref
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg_name = case.split('_')[0]
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, int(z['weight_seed']))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=1, ctx_len=int(z['ctx_len']))
+    ref = torch.from_numpy(z['eps'])
+    sd_gpu = {k: v.cuda() for k, v in sd.items()}
+    orig_arange = torch.arange
+    with torch.autocast('cuda', dtype=torch.float16):
+        torch.arange = lambda *a, **k: orig_arange(*a, **{**k, 'device': 'cuda'})
+        try:
+            eps_ac = unet_ref.unet_forward(sd_gpu, cfg, x.cuda(), t.cuda(), ctx.cuda())
+        finally:
+            torch.arange = orig_arange
+    eps_hip = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    e_ac = (eps_ac.float().cpu() - ref).abs().max().item()
+    e_hip = (eps_hip.float().cpu() - ref).abs().max().item()
+    e_x = (eps_hip.float().cpu() - eps_ac.float().cpu()).abs().max().item()
+    print(f'[noise floor {case}] HIP-vs-fp32 {e_hip:.3e} | torch-fp16-autocast-vs-fp32 {e_ac:.3e} | HIP-vs-autocast {e_x:.3e}',
+          flush=True)
+    assert e_hip <= max(TOL, e_ac)
+
+
+def test_context_cache_and_repeatability():
+    """Same inputs twice (second call reuses the cached cross-attention K/V) must give identical eps; a changed
+    context must change it; float timesteps (DPM-Solver passes floats, dpm_solver.py:284-285) are accepted."""
+    m, sd = _model('tiny', 0)
+    x, t, ctx = make_inputs(TINY, 2, 16, 16, seed=5)
+    xc, tc, cc = x.cuda(), t.cuda(), ctx.cuda()
+    e1 = m(xc, tc, context=cc)
+    e2 = m(xc, tc, context=cc)
+    assert torch.equal(e1, e2)
+    e3 = m(xc, tc, context=cc * 1.5)
+    assert not torch.equal(e1, e3)
+    e4 = m(xc, tc, context=cc)
+    assert torch.equal(e1, e4)
+    e5 = m(xc, tc.float(), context=cc)
+    assert torch.allclose(e1, e5, atol=1e-6)
+    m.pin_context(cc)
+    e6 = m(xc, tc, context=cc.clone())
+    m.unpin_context()
+    assert torch.equal(e1, e6)
+
+
+def test_refuses_cpu_and_bad_config():
+    from stable_diffusion_amd import UNetModelHIP
+    m, sd = _model('tiny', 0)
+    x, t, ctx = make_inputs(TINY, 1, 8, 8)
+    with pytest.raises(RuntimeError):
+        m(x, t, context=ctx)                       # CPU tensors: no fallback
+    with pytest.raises(Exception):
+        m(x.cuda()[:, :, :7, :], t.cuda(), context=ctx.cuda())   # H not divisible by 8
+    with pytest.raises(NotImplementedError):
+        UNetModelHIP(image_size=32, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2,
+                     attention_resolutions=[1], legacy=True)
