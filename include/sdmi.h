@@ -88,10 +88,10 @@ int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float*
 
 /* ---- kernel-level entry points (parity tests and micro-benchmarks; same kernels the UNet uses) ---------- */
 typedef struct sdmi_igemm_desc {
-  const void* a0; const void* a1;       /* fp16 NHWC sources (a1 optional: channel concat) */
-  int32_t c0, c1, lda0, lda1;
+  const void* a0; const void* a1; const void* a2;   /* fp16 NHWC sources, channel concat [a0|a1|a2] (a1, a2 optional) */
+  int32_t c0, c1, c2, lda0, lda1, lda2;
   int32_t B, Hin, Win, Hout, Wout, ksize, stride, up;
-  const void* w;                        /* fp16 [N][K], K = ksize*ksize*(c0+c1) ordered (ky,kx,cin) */
+  const void* w;                        /* fp16 [N][K], K = ksize*ksize*(c0+c1+c2) ordered (ky,kx,cin) */
   int32_t N;
   int32_t mode;                         /* 0 plain, 1 GEGLU (w/bias packed by sdmi_k_pack_geglu), 2 per-head scatter */
   const float* bias; const float* rowvec; int32_t ld_rowvec;
@@ -99,7 +99,8 @@ typedef struct sdmi_igemm_desc {
   float* out_f32; void* out_f16; int32_t ldo;
   void* seg_dst[3]; int32_t seg_kind[3];
   int32_t heads, dh, ntok, ntok_pad, segC;
-  int32_t splitk;                       /* 1 none, 0 auto, >1 forced */
+  int32_t splitk;                       /* 1 none, 0 auto, >1 forced (plain mode; needs splitk_ws) */
+  float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs [splitk][M][N] */
   int32_t tile;                         /* -1 auto, 0 128x128, 1 128x64, 2 64x64 */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
 } sdmi_igemm_desc;
@@ -107,14 +108,15 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
 int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
                      int nkv_pad, int d, float scale, void* stream);
-/* GroupNorm(32) over cat(x0,x1) fp32 NHWC; any of out_f16 / out_f32 / raw_f16 may be NULL */
+/* GroupNorm(32) over cat(x0,x1) fp32 NHWC; any of the outputs may be NULL.  out_lo / raw_lo = fp16(v - fp16(v)):
+ * the low halves of split-fp16 operands (3-pass 1x1 convs) */
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
-                     const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16,
-                     float* partial_ws, int64_t partial_floats, void* stream);
+                     const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
+                     void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream);
 int64_t sdmi_k_groupnorm_ws_floats(int B, int HW);
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
                      void* stream);
-int sdmi_k_cast_f16(const float* x, void* out_f16, int64_t n, void* stream);
+int sdmi_k_cast_f16(const float* x, void* out_f16, void* out_lo, int64_t n, void* stream);
 int sdmi_k_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, void* stream);
 int sdmi_k_small_linear(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out, int B,
                         int N, int K, int silu_in, void* stream);
@@ -124,6 +126,8 @@ int sdmi_k_conv_out(const float* h_nhwc, const float* w_ohwi, const float* bias,
                     int Cin, int Cout, void* stream);
 int sdmi_k_pack_conv_weight(const float* w_oihw, void* dst_f16, int O, int I, int KH, int KW, void* stream);
 int sdmi_k_pack_conv_out(const float* w_oihw, float* dst_ohwi, int O, int I, void* stream);
+/* [N][K] fp32 -> fp16 [N][3K] = [hi | hi | lo] for the 3-pass split-fp16 1x1 convs */
+int sdmi_k_pack_split3(const float* w, void* dst_f16, int N, int K, void* stream);
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst_f16, float* bdst, int N, int K, void* stream);
 /* per-launch timing of the library's kernels (HIP events on the launch stream): begin, run forwards, then end
  * writes a JSON array [{"name","launches","ms","flops","bytes"}] (algorithmic flops / bytes per kernel class) */

@@ -17,8 +17,9 @@ class UNetCfg(C.Structure):
 
 
 class IGemmDesc(C.Structure):
-    _fields_ = [('a0', c_ptr), ('a1', c_ptr),
-                ('c0', C.c_int32), ('c1', C.c_int32), ('lda0', C.c_int32), ('lda1', C.c_int32),
+    _fields_ = [('a0', c_ptr), ('a1', c_ptr), ('a2', c_ptr),
+                ('c0', C.c_int32), ('c1', C.c_int32), ('c2', C.c_int32),
+                ('lda0', C.c_int32), ('lda1', C.c_int32), ('lda2', C.c_int32),
                 ('B', C.c_int32), ('Hin', C.c_int32), ('Win', C.c_int32), ('Hout', C.c_int32), ('Wout', C.c_int32),
                 ('ksize', C.c_int32), ('stride', C.c_int32), ('up', C.c_int32),
                 ('w', c_ptr), ('N', C.c_int32), ('mode', C.c_int32),
@@ -27,7 +28,8 @@ class IGemmDesc(C.Structure):
                 ('out_f32', c_ptr), ('out_f16', c_ptr), ('ldo', C.c_int32),
                 ('seg_dst', c_ptr * 3), ('seg_kind', C.c_int32 * 3),
                 ('heads', C.c_int32), ('dh', C.c_int32), ('ntok', C.c_int32), ('ntok_pad', C.c_int32),
-                ('segC', C.c_int32), ('splitk', C.c_int32), ('tile', C.c_int32), ('dma', C.c_int32)]
+                ('segC', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', c_ptr), ('splitk_ws_floats', C.c_int64),
+                ('tile', C.c_int32), ('dma', C.c_int32)]
 
 
 _SIGS = {
@@ -49,10 +51,10 @@ _SIGS = {
     'sdmi_k_attention': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, c_ptr]),
     'sdmi_k_groupnorm': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, C.c_int,
-                                   c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
+                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_groupnorm_ws_floats': (C.c_int64, [C.c_int, C.c_int]),
     'sdmi_k_layernorm': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
-    'sdmi_k_cast_f16': (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_k_cast_f16': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_timestep_embedding': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_small_linear': (C.c_int, [c_ptr, C.c_int, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, c_ptr]),
@@ -60,6 +62,7 @@ _SIGS = {
     'sdmi_k_conv_out': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_conv_weight': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_conv_out': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
+    'sdmi_k_pack_split3': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_geglu': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_profile_begin': (C.c_int, []),
     'sdmi_profile_end': (C.c_int, [C.c_char_p, C.c_int]),

@@ -50,7 +50,8 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
-        cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        extra = ['-ffp-contract=off'] if src == 'sampler.hip' else []    # bit-exact fp32 op order (see sampler.hip)
+        cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')

@@ -96,15 +96,16 @@ int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float*
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   SDMI_CHECK(d, "null descriptor");
   IGemmParams p;
-  p.a0 = (const f16*)d->a0; p.a1 = (const f16*)d->a1; p.c0 = d->c0; p.c1 = d->c1; p.lda0 = d->lda0; p.lda1 = d->lda1;
+  p.a0 = (const f16*)d->a0; p.a1 = (const f16*)d->a1; p.a2 = (const f16*)d->a2;
+  p.c0 = d->c0; p.c1 = d->c1; p.c2 = d->c2; p.lda0 = d->lda0; p.lda1 = d->lda1; p.lda2 = d->lda2;
   p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
   p.ksize = d->ksize; p.stride = d->stride; p.up = d->up;
-  p.w = (const f16*)d->w; p.M = d->B * d->Hout * d->Wout; p.N = d->N; p.K = d->ksize * d->ksize * (d->c0 + d->c1);
+  p.w = (const f16*)d->w; p.M = d->B * d->Hout * d->Wout; p.N = d->N; p.K = d->ksize * d->ksize * (d->c0 + d->c1 + d->c2);
   p.mode = d->mode; p.bias = d->bias; p.rowvec = d->rowvec; p.ld_rowvec = d->ld_rowvec;
   p.residual = d->residual; p.ldr = d->ldr; p.out_f32 = d->out_f32; p.out_f16 = (f16*)d->out_f16; p.ldo = d->ldo;
   for (int i = 0; i < 3; ++i) { p.seg_dst[i] = (f16*)d->seg_dst[i]; p.seg_kind[i] = d->seg_kind[i]; }
   p.heads = d->heads; p.dh = d->dh; p.ntok = d->ntok; p.ntok_pad = d->ntok_pad; p.segC = d->segC;
-  p.splitk = d->splitk;
+  p.splitk = d->splitk; p.splitk_ws = d->splitk_ws; p.splitk_ws_floats = d->splitk_ws_floats;
   if (zero_page(&p.zero_page)) return -1;
   IGemmTune t; t.tile = d->tile; t.dma = d->dma;
   return launch_igemm(p, t, (hipStream_t)stream);
@@ -118,20 +119,21 @@ int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, in
 }
 int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { return gn_partial_floats(B, HW); }
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
-                     const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16,
-                     float* partial_ws, int64_t partial_floats, void* stream) {
+                     const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
+                     void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream) {
   SDMI_CHECK(partial_floats >= gn_partial_floats(B, HW), "groupnorm workspace too small");
   GroupNormParams g;
   g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = HW; g.gamma = gamma; g.beta = beta; g.eps = eps;
-  g.silu = silu; g.out_f16 = (f16*)out_f16; g.out_f32 = out_f32; g.raw_f16 = (f16*)raw_f16; g.partial = partial_ws;
+  g.silu = silu; g.out_f16 = (f16*)out_f16; g.out_f32 = out_f32; g.raw_f16 = (f16*)raw_f16; g.out_lo = (f16*)out_lo; g.raw_lo = (f16*)raw_lo;
+  g.partial = partial_ws;
   return launch_groupnorm(g, (hipStream_t)stream);
 }
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
                      void* stream) {
   return launch_layernorm(x, gamma, beta, (f16*)out_f16, M, C, eps, (hipStream_t)stream);
 }
-int sdmi_k_cast_f16(const float* x, void* out_f16, int64_t n, void* stream) {
-  return launch_cast_f16(x, (f16*)out_f16, n, (hipStream_t)stream);
+int sdmi_k_cast_f16(const float* x, void* out_f16, void* out_lo, int64_t n, void* stream) {
+  return launch_cast_f16(x, (f16*)out_f16, (f16*)out_lo, n, (hipStream_t)stream);
 }
 int sdmi_k_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, void* stream) {
   return launch_timestep_embedding(t_i64, t_f32, out, B, dim, (hipStream_t)stream);
@@ -153,6 +155,9 @@ int sdmi_k_pack_conv_weight(const float* w, void* dst, int O, int I, int KH, int
 }
 int sdmi_k_pack_conv_out(const float* w, float* dst, int O, int I, void* stream) {
   return launch_pack_conv_out(w, dst, O, I, (hipStream_t)stream);
+}
+int sdmi_k_pack_split3(const float* w, void* dst, int N, int K, void* stream) {
+  return launch_pack_split3(w, (f16*)dst, N, K, (hipStream_t)stream);
 }
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst, float* bdst, int N, int K, void* stream) {
   return launch_pack_geglu(w, bias, (f16*)wdst, bdst, N, K, (hipStream_t)stream);

@@ -42,9 +42,9 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 
 struct IGemmParams {
-  const f16* a0 = nullptr; const f16* a1 = nullptr;   // A sources (a1 optional: channel concat [a0 | a1])
-  int c0 = 0, c1 = 0;                                  // channels taken from each source (Cin = c0 + c1)
-  int lda0 = 0, lda1 = 0;                              // row pitch (elements) of each source
+  const f16* a0 = nullptr; const f16* a1 = nullptr; const f16* a2 = nullptr;   // A sources, channel concat [a0 | a1 | a2]
+  int c0 = 0, c1 = 0, c2 = 0;                          // channels taken from each source (Cin = c0 + c1 + c2)
+  int lda0 = 0, lda1 = 0, lda2 = 0;                    // row pitch (elements) of each source
   int B = 1, Hin = 1, Win = 1;                         // source spatial dims (M = B*Hout*Wout)
   int Hout = 1, Wout = 1;
   int ksize = 1, stride = 1, up = 0;
@@ -62,8 +62,10 @@ struct IGemmParams {
   f16* seg_dst[3] = {nullptr, nullptr, nullptr};
   int seg_kind[3] = {0, 0, 0};
   int heads = 0, dh = 0, ntok = 0, ntok_pad = 0, segC = 0;
-  // split-K: >1 => fp32 atomicAdd into out_f32 (which the caller pre-initialised with the epilogue terms)
-  int splitk = 1;
+  // split-K (plain mode only): every split stores its partial tile into a private fp32 slab of splitk_ws
+  // ([split][M][N]); a second kernel sums the slabs in a fixed order and applies the epilogue (deterministic).
+  int splitk = 1;                                      // 1 none, 0 auto, >1 forced
+  float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
 };
 
@@ -94,14 +96,16 @@ struct GroupNormParams {
   f16* out_f16 = nullptr;      // [B*HW][C] normalised (+SiLU)
   float* out_f32 = nullptr;    // same in fp32 (used by the output head)
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
-  float* partial = nullptr;    // workspace [B][nchunk][32][2]
+  f16* out_lo = nullptr;       // optional: fp16(y - float(fp16(y)))   -- low half of a split-fp16 operand
+  f16* raw_lo = nullptr;       // optional: same for the raw copy
+  float* partial = nullptr;    // workspace, gn_partial_floats(B, HW) floats
 };
 int gn_partial_floats(int B, int HW);
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,
                      hipStream_t stream);
-int launch_cast_f16(const float* x, f16* out, int64_t n, hipStream_t stream);
+int launch_cast_f16(const float* x, f16* out, f16* out_lo, int64_t n, hipStream_t stream);
 
 // fp32 "small" path
 int launch_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, hipStream_t s);
@@ -111,13 +115,12 @@ int launch_conv_in(const float* x_nchw, const float* w, const float* bias, float
                    int W, int Cout, hipStream_t s);
 int launch_conv_out(const float* h_nhwc, const float* w_khwc, const float* bias, float* out_nchw, int B, int H, int W,
                     int Cin, int Cout, hipStream_t s);
-// out = bias[n] + rowvec[b][n] + residual   (pre-initialisation for split-K atomics)
-int launch_epilogue_init(float* out, int ldo, const float* bias, const float* rowvec, int ld_rowvec,
-                         const float* residual, int ldr, int M, int N, int rows_per_batch, hipStream_t s);
 
 // weight packing (device pointers, fp32 reference layouts -> packed)
 int launch_pack_conv_weight(const float* w_oihw, f16* dst, int O, int I, int KH, int KW, hipStream_t s);  // -> [O][KH][KW][I]
 int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0, int dst_ld, hipStream_t s);
+// split-fp16 weights for the 3-pass 1x1 convs: dst [N][3K] = [hi | hi | lo], lo = fp16(w - float(hi))
+int launch_pack_split3(const float* w, f16* dst, int N, int K, hipStream_t s);
 int launch_pack_geglu(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K, hipStream_t s);
 int launch_pack_conv_out(const float* w_oihw, float* dst, int O, int I, hipStream_t s);   // -> [O][3][3][I] fp32
 

@@ -72,7 +72,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   // ---- per-row gather metadata ---------------------------------------------------------------------
   const int HWout = p.Hout * p.Wout;
-  const int Cin = p.c0 + p.c1;
+  const int Cin = p.c0 + p.c1 + p.c2;
   const int pad = (p.ksize == 3) ? 1 : 0;
   const int Hv = p.up ? 2 * p.Hin : p.Hin;
   const int Wv = p.up ? 2 * p.Win : p.Win;
@@ -107,7 +107,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     const int ky = (p.ksize == 3) ? tap / 3 : 0;
     const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
     const f16* src; int ld, coff;
-    if (cin0 < p.c0) { src = p.a0; ld = p.lda0; coff = cin0; } else { src = p.a1; ld = p.lda1; coff = cin0 - p.c0; }
+    if (cin0 < p.c0) { src = p.a0; ld = p.lda0; coff = cin0; }
+    else if (cin0 < p.c0 + p.c1) { src = p.a1; ld = p.lda1; coff = cin0 - p.c0; }
+    else { src = p.a2; ld = p.lda2; coff = cin0 - p.c0 - p.c1; }
     unsigned char* As = smem + stage * STAGE_BYTES;
     unsigned char* Bs = As + BM * 128;
 #pragma unroll
@@ -189,7 +191,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
   if (p.mode == EPI_PLAIN) {
-    const bool atomic = p.splitk > 1;
+    const bool atomic = p.splitk > 1;      // split-K: raw partial sums go to this split's slab
+    float* slab = atomic ? (p.splitk_ws + (size_t)split * p.M * p.N) : nullptr;
     float bias_v[TN];
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
           if (n >= p.N) continue;
           float v = acc[i][j][r];
           if (atomic) {
-            unsafeAtomicAdd(p.out_f32 + (size_t)m * p.ldo + n, v);
+            slab[(size_t)m * p.N + n] = v;
           } else {
             v += bias_v[j];
             if (rv) v += rv[n];
@@ -267,18 +270,22 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   }
 }
 
-__global__ void epilogue_init_kernel(float* out, int ldo, const float* bias, const float* rowvec, int ld_rowvec,
-                                     const float* residual, int ldr, int M, int N, int rows_per_batch) {
+// out = sum_s slab[s] + bias + rowvec[batch] + residual   (fixed summation order -> deterministic)
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int nsplit) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t total = (int64_t)M * (N / 4);
-  if (idx >= total) return;
-  const int m = (int)(idx / (N / 4));
-  const int n = (int)(idx - (int64_t)m * (N / 4)) * 4;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (bias) v += *(const f32x4*)(bias + n);
-  if (rowvec) v += *(const f32x4*)(rowvec + (size_t)(m / rows_per_batch) * ld_rowvec + n);
-  if (residual) v += *(const f32x4*)(residual + (size_t)m * ldr + n);
-  *(f32x4*)(out + (size_t)m * ldo + n) = v;
+  const int nq = p.N / 4;
+  if (idx >= (int64_t)p.M * nq) return;
+  const int m = (int)(idx / nq);
+  const int n = (int)(idx - (int64_t)m * nq) * 4;
+  const size_t slab_sz = (size_t)p.M * p.N;
+  const float* src = p.splitk_ws + (size_t)m * p.N + n;
+  f32x4 v = *(const f32x4*)src;
+  for (int s = 1; s < nsplit; ++s) v += *(const f32x4*)(src + s * slab_sz);
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / (p.Hout * p.Wout)) * p.ld_rowvec + n);
+  if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+  if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
+  if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N>
@@ -305,20 +312,16 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
     hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false>), grid, block, 0, stream, q, tiles_m, tiles_n,
                        kt_per_split);
   SDMI_HIP_OK(hipGetLastError());
+  if (nsplit > 1) {
+    const int64_t total = (int64_t)p.M * (p.N / 4);
+    ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, q, nsplit);
+    SDMI_HIP_OK(hipGetLastError());
+  }
   return 0;
 }
 
 }  // namespace
-
-int launch_epilogue_init(float* out, int ldo, const float* bias, const float* rowvec, int ld_rowvec,
-                         const float* residual, int ldr, int M, int N, int rows_per_batch, hipStream_t s) {
-  SDMI_CHECK(N % 4 == 0 && ldo % 4 == 0 && (residual == nullptr || ldr % 4 == 0), "epilogue_init needs N % 4 == 0");
-  const int64_t total = (int64_t)M * (N / 4);
-  hipLaunchKernelGGL(epilogue_init_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, out, ldo, bias,
-                     rowvec, ld_rowvec, residual, ldr, M, N, rows_per_batch);
-  SDMI_HIP_OK(hipGetLastError());
-  return 0;
-}
 
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
@@ -328,13 +331,14 @@ static int env_int(const char* name, int dflt) {
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream) {
   SDMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SDMI_CHECK(p.ksize == 1 || p.ksize == 3, "ksize must be 1 or 3");
-  const int Cin = p.c0 + p.c1;
-  SDMI_CHECK(p.K == p.ksize * p.ksize * Cin, "K != ksize^2 * (c0 + c1)");
-  SDMI_CHECK(Cin % BK == 0 && p.c0 % BK == 0, "channel counts must be multiples of 64");
+  const int Cin = p.c0 + p.c1 + p.c2;
+  SDMI_CHECK(p.K == p.ksize * p.ksize * Cin, "K != ksize^2 * (c0 + c1 + c2)");
+  SDMI_CHECK(Cin % BK == 0 && p.c0 % BK == 0 && p.c1 % BK == 0, "channel counts must be multiples of 64");
   SDMI_CHECK(p.lda0 % 8 == 0 && (p.a1 == nullptr || p.lda1 % 8 == 0), "A row pitch must be a multiple of 8 halves");
   SDMI_CHECK(p.zero_page != nullptr, "zero page missing");
   SDMI_CHECK(p.M == p.B * p.Hout * p.Wout, "M != B * Hout * Wout");
   SDMI_CHECK(p.c1 == 0 || p.a1 != nullptr, "second A source missing");
+  SDMI_CHECK(p.c2 == 0 || (p.a2 != nullptr && p.lda2 % 8 == 0), "third A source missing");
   if (p.mode == EPI_GEGLU) SDMI_CHECK(p.N % 64 == 0 && p.out_f16 != nullptr, "GEGLU needs N % 64 == 0 and an fp16 output");
   if (p.mode == EPI_HEADS) SDMI_CHECK(p.segC > 0 && p.dh > 0 && p.N % p.segC == 0 && p.N / p.segC <= 3, "bad head scatter");
 
@@ -353,19 +357,22 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64};
   int splitk = p.splitk;
   const int nkt = p.K / BK;
-  if (splitk <= 0) {  // auto
+  static const int env_split = env_int("SDMI_SPLITK", -1);     // 1 disables split-K everywhere
+  const bool can_split = p.mode == EPI_PLAIN && p.splitk_ws && p.N % 4 == 0 && p.ldo % 4 == 0 &&
+                         (p.residual == nullptr || p.ldr % 4 == 0);
+  if (env_split >= 0 && splitk == 0) splitk = env_split;
+  if (splitk <= 0) {  // auto: fill the 256 CUs when the tile grid alone cannot, keeping >= 4 k-tiles per split
     splitk = 1;
-    if (p.mode == EPI_PLAIN && p.out_f32 && !p.out_f16) {
+    if (can_split) {
       const long blocks = (long)cdiv(p.M, BMs[tile]) * cdiv(p.N, BNs[tile]);
-      while (blocks * splitk < 256 && nkt / (splitk * 2) >= 4 && splitk < 16) splitk *= 2;
+      while (blocks * splitk < 256 && nkt / (splitk * 2) >= 4 && splitk < 16 &&
+             (int64_t)(splitk * 2) * p.M * p.N <= p.splitk_ws_floats)
+        splitk *= 2;
     }
   }
   if (splitk > 1) {
-    SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && !p.out_f16, "split-K needs a plain fp32-only output");
-    SDMI_CHECK(p.N % 4 == 0, "split-K needs N % 4 == 0");
-    if (launch_epilogue_init(p.out_f32, p.ldo, p.bias, p.rowvec, p.ld_rowvec, p.residual, p.ldr, p.M, p.N,
-                             p.Hout * p.Wout, stream))
-      return -1;
+    SDMI_CHECK(can_split, "split-K needs plain mode, a slab workspace and N / ldo / ldr multiples of 4");
+    SDMI_CHECK((int64_t)splitk * p.M * p.N <= p.splitk_ws_floats, "split-K workspace too small");
   }
   switch (tile) {
     case 0: return launch_cfg<128, 128, 2, 2>(p, dma, splitk, stream);

@@ -11,28 +11,35 @@
 namespace sdmi {
 namespace {
 
-constexpr int GN_CHUNK = 64;    // pixels per statistics block
+constexpr int GN_CHUNK = 8;     // pixels per statistics block (fully unrolled: 8 independent loads in flight)
 constexpr int GN_MAXC = 2560 * 2;
 
 __device__ __forceinline__ f32x4 load_cat4(const float* x0, const float* x1, int c0, int c1, size_t pix, int c) {
   return (c < c0) ? *(const f32x4*)(x0 + pix * c0 + c) : *(const f32x4*)(x1 + pix * c1 + (c - c0));
 }
+__device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp16(v)))
+  f16x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) r[j] = (f16)(v[j] - (float)(f16)v[j]);
+  return r;
+}
 
 // partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g)
-__global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk) {
+__global__ void __launch_bounds__(128) gn_stats_kernel(GroupNormParams p, int nchunk) {
   __shared__ float csum[GN_MAXC], csq[GN_MAXC];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int pix0 = chunk * GN_CHUNK;
   const int npix = min(GN_CHUNK, p.HW - pix0);
-  for (int q = tid; q < C / 4; q += 256) {
+  for (int q = tid; q < C / 4; q += 128) {
     const int c = q * 4;
+    f32x4 v[GN_CHUNK];
+#pragma unroll
+    for (int i = 0; i < GN_CHUNK; ++i)
+      v[i] = (i < npix) ? load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + i, c) : f32x4{0, 0, 0, 0};
     f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
-    for (int i = 0; i < npix; ++i) {
-      const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + i, c);
-      s += v;
-      ss += v * v;
-    }
+#pragma unroll
+    for (int i = 0; i < GN_CHUNK; ++i) { s += v[i]; ss += v[i] * v[i]; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { csum[c + j] = s[j]; csq[c + j] = ss[j]; }
   }
@@ -46,26 +53,36 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
   }
 }
 
+// stats[b][g] = {mean, rstd}: 8 threads per group sum the chunk partials (fp64), fixed order
+__global__ void __launch_bounds__(256) gn_finalize_kernel(GroupNormParams p, int nchunk, float* stats) {
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int g = tid >> 3, sub = tid & 7;
+  const int C = p.c0 + p.c1;
+  double s = 0.0, ss = 0.0;
+  for (int ch = sub; ch < nchunk; ch += 8) {
+    const float* src = p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2;
+    s += (double)src[0]; ss += (double)src[1];
+  }
+#pragma unroll
+  for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  if (sub == 0) {
+    const double n = (double)(C / 32) * (double)p.HW;
+    const double mean = s / n;
+    double var = ss / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    stats[(b * 32 + g) * 2 + 0] = (float)mean;
+    stats[(b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+  }
+}
+
 constexpr int GN_APPLY_PIX = 8;
 
-__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nchunk) {
+__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const float* stats) {
   __shared__ float s_mean[32], s_rstd[32];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
-  if (tid < 32) {
-    double s = 0.0, ss = 0.0;
-    for (int ch = 0; ch < nchunk; ++ch) {
-      const float* src = p.partial + ((size_t)(b * nchunk + ch) * 32 + tid) * 2;
-      s += (double)src[0]; ss += (double)src[1];
-    }
-    const double n = (double)cpg * (double)p.HW;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    s_mean[tid] = (float)mean;
-    s_rstd[tid] = (float)(1.0 / sqrt(var + (double)p.eps));
-  }
+  if (tid < 32) { s_mean[tid] = stats[(b * 32 + tid) * 2]; s_rstd[tid] = stats[(b * 32 + tid) * 2 + 1]; }
   __syncthreads();
   const int pix0 = blockIdx.x * GN_APPLY_PIX;
   const int npix = min(GN_APPLY_PIX, p.HW - pix0);
@@ -87,8 +104,10 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nc
     }
     const size_t o = pix * C + c;
     if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+    if (p.out_lo) *(f16x4*)(p.out_lo + o) = lo_half(y);
     if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
     if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v);
   }
 }
 
@@ -138,16 +157,17 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const fl
   }
 }
 
-__global__ void cast_f16_kernel(const float* x, f16* out, int64_t n4) {
+__global__ void cast_f16_kernel(const float* x, f16* out, f16* out_lo, int64_t n4) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n4) return;
   const f32x4 v = *(const f32x4*)(x + i * 4);
   *(f16x4*)(out + i * 4) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  if (out_lo) *(f16x4*)(out_lo + i * 4) = lo_half(v);
 }
 
 }  // namespace
 
-int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64; }
+int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64 + B * 64; }
 
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int C = p.c0 + p.c1;
@@ -157,8 +177,10 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int nchunk = cdiv(p.HW, GN_CHUNK);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, nchunk);
+  float* stats = p.partial + (size_t)p.B * nchunk * 64;
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(128), 0, stream, p, nchunk);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, stream, p, nchunk, stats);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, (const float*)stats);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -174,11 +196,11 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, f16*
   return 0;
 }
 
-int launch_cast_f16(const float* x, f16* out, int64_t n, hipStream_t stream) {
+int launch_cast_f16(const float* x, f16* out, f16* out_lo, int64_t n, hipStream_t stream) {
   SDMI_CHECK(n % 4 == 0, "cast: n % 4 != 0");
   const int64_t n4 = n / 4;
   ProfScope ps("cast_f16", 0.0, (double)n * 6.0, stream);
-  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, out, n4);
+  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, out, out_lo, n4);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

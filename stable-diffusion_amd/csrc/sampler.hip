@@ -7,41 +7,50 @@
 #include "prof.h"
 #include <math.h>
 
+// every product / sum below must round on its own, exactly like the reference's separate torch ops
+#pragma clang fp contract(off)
+
 namespace sdmi {
 namespace {
 
 __global__ void __launch_bounds__(256) sampler_step_kernel(SamplerStepParams p, float sqrt_at, float sqrt_aprev,
                                                            float dir_coef) {
+#pragma clang fp contract(off)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= p.n) return;
   float e_t;
   if (p.cfg) {
     const float eu = p.eps_model[i], ec = p.eps_model[p.n + i];
-    e_t = __fadd_rn(eu, __fmul_rn(p.scale, __fsub_rn(ec, eu)));   // e_u + s * (e_c - e_u)
+    const float d = ec - eu;
+    const float sd = p.scale * d;
+    e_t = eu + sd;                                   // e_u + s * (e_c - e_u)
   } else {
     e_t = p.eps_model[i];
   }
   if (p.e_t_out) p.e_t_out[i] = e_t;
   float ep;
   switch (p.mode) {
-    case 1: ep = __fdiv_rn(__fsub_rn(__fmul_rn(3.f, e_t), p.old0[i]), 2.f); break;
-    case 2:
-      ep = __fdiv_rn(__fadd_rn(__fsub_rn(__fmul_rn(23.f, e_t), __fmul_rn(16.f, p.old0[i])), __fmul_rn(5.f, p.old1[i])), 12.f);
-      break;
-    case 3:
-      ep = __fdiv_rn(__fsub_rn(__fadd_rn(__fsub_rn(__fmul_rn(55.f, e_t), __fmul_rn(59.f, p.old0[i])),
-                                         __fmul_rn(37.f, p.old1[i])),
-                               __fmul_rn(9.f, p.old2[i])),
-                     24.f);
-      break;
-    case 4: ep = __fdiv_rn(__fadd_rn(p.old0[i], e_t), 2.f); break;
+    case 1: { const float a = 3.f * e_t; const float b = a - p.old0[i]; ep = b / 2.f; break; }
+    case 2: {
+      const float a = 23.f * e_t, b = 16.f * p.old0[i], c = 5.f * p.old1[i];
+      const float ab = a - b; const float abc = ab + c; ep = abc / 12.f; break;
+    }
+    case 3: {
+      const float a = 55.f * e_t, b = 59.f * p.old0[i], c = 37.f * p.old1[i], d = 9.f * p.old2[i];
+      const float ab = a - b; const float abc = ab + c; const float abcd = abc - d; ep = abcd / 24.f; break;
+    }
+    case 4: { const float a = p.old0[i] + e_t; ep = a / 2.f; break; }
     default: ep = e_t; break;
   }
   const float x = p.x[i];
-  const float pred = __fdiv_rn(__fsub_rn(x, __fmul_rn(p.sqrt_1m_at, ep)), sqrt_at);
-  float xp = __fadd_rn(__fmul_rn(sqrt_aprev, pred), __fmul_rn(dir_coef, ep));
-  const float nz = p.noise ? __fmul_rn(p.sigma, p.noise[i]) : 0.f;
-  xp = __fadd_rn(xp, nz);
+  const float t1 = p.sqrt_1m_at * ep;
+  const float t2 = x - t1;
+  const float pred = t2 / sqrt_at;
+  const float t3 = sqrt_aprev * pred;
+  const float t4 = dir_coef * ep;
+  float xp = t3 + t4;
+  const float nz = p.noise ? p.sigma * p.noise[i] : 0.f;
+  xp = xp + nz;
   p.x_prev[i] = xp;
   if (p.pred_x0) p.pred_x0[i] = pred;
 }

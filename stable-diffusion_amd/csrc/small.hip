@@ -171,6 +171,17 @@ __global__ void pack_rows_kernel(const float* w, f16* dst, int rows, int cols, i
   const int r = (int)(idx / cols), c = (int)(idx - (int64_t)r * cols);
   dst[(int64_t)(dst_row0 + r) * dst_ld + c] = (f16)w[idx];
 }
+// split-fp16 weight for the 3-pass 1x1 convs: dst[n] = [hi(K) | hi(K) | lo(K)]
+__global__ void pack_split3_kernel(const float* w, f16* dst, int N, int K) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (int64_t)N * K) return;
+  const int n = (int)(idx / K), k = (int)(idx - (int64_t)n * K);
+  const float v = w[idx];
+  const f16 hi = (f16)v;
+  const f16 lo = (f16)(v - (float)hi);
+  f16* d = dst + (int64_t)n * 3 * K;
+  d[k] = hi; d[K + k] = hi; d[2 * K + k] = lo;
+}
 // GEGLU: dst row 64q + j  <- value row 32q + j (j < 32) | gate row N/2 + 32q + (j - 32)
 __global__ void pack_geglu_kernel(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -260,6 +271,12 @@ int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0,
   const int64_t total = (int64_t)rows * cols;
   hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, rows, cols,
                      dst_row0, dst_ld);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+int launch_pack_split3(const float* w, f16* dst, int N, int K, hipStream_t s) {
+  const int64_t total = (int64_t)N * K;
+  hipLaunchKernelGGL(pack_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, N, K);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -43,6 +43,8 @@ int UNet::build(const sdmi_unet_cfg& c) {
   SDMI_CHECK(c.num_heads >= 1 && c.transformer_depth >= 1, "num_heads / transformer_depth");
   const int mc = c.model_channels;
   te_ = 4 * mc;
+  if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
+  const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
 
   auto add_res = [&](const std::string& p, int cin, int cout) {
     Layer L; L.kind = L_RES; L.prefix = p; L.cin = cin; L.cout = cout;
@@ -130,7 +132,7 @@ int UNet::build(const sdmi_unet_cfg& c) {
         expect(p + ".out_layers.3.weight", {co, co, 3, 3}, W_CONV, (void**)&L.w16[1]);
         expect(p + ".out_layers.3.bias", {co}, W_F32, (void**)&L.f32[5]);
         if (ci != co) {
-          expect(p + ".skip_connection.weight", {co, ci, 1, 1}, W_CONV, (void**)&L.w16[2]);
+          expect(p + ".skip_connection.weight", {co, ci, 1, 1}, K1, (void**)&L.w16[2]);
           expect(p + ".skip_connection.bias", {co}, W_F32, (void**)&L.f32[6]);
         }
         break;
@@ -138,9 +140,9 @@ int UNet::build(const sdmi_unet_cfg& c) {
         const int64_t C = ci, CD = cfg_.context_dim;
         expect(p + ".norm.weight", {C}, W_F32, (void**)&L.f32[0]);
         expect(p + ".norm.bias", {C}, W_F32, (void**)&L.f32[1]);
-        expect(p + ".proj_in.weight", {C, C, 1, 1}, W_CONV, (void**)&L.w16[0]);
+        expect(p + ".proj_in.weight", {C, C, 1, 1}, K1, (void**)&L.w16[0]);
         expect(p + ".proj_in.bias", {C}, W_F32, (void**)&L.f32[2]);
-        expect(p + ".proj_out.weight", {C, C, 1, 1}, W_CONV, (void**)&L.w16[1]);
+        expect(p + ".proj_out.weight", {C, C, 1, 1}, K1, (void**)&L.w16[1]);
         expect(p + ".proj_out.bias", {C}, W_F32, (void**)&L.f32[3]);
         L.tb.resize(cfg_.transformer_depth);
         for (int d = 0; d < cfg_.transformer_depth; ++d) {
@@ -240,6 +242,10 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
       rc = dev_alloc(s.dst, numel * sizeof(f16));
       if (!rc) rc = launch_pack_conv_weight(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], (int)shape[2], (int)shape[3], stream);
       break;
+    case W_SPLIT3:
+      rc = dev_alloc(s.dst, 3 * numel * sizeof(f16));
+      if (!rc) rc = launch_pack_split3(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], stream);
+      break;
     case W_CONV_OUT:
       rc = dev_alloc(s.dst, numel * sizeof(float));
       if (!rc) rc = launch_pack_conv_out(dptr, (float*)*s.dst, (int)shape[0], (int)shape[1], stream);
@@ -317,6 +323,7 @@ struct Fwd {
   UNet* u; hipStream_t s; bool dry; int B, Lctx;
   Arena persist, scratch;
   float* gn_partial = nullptr;
+  float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   float* emb_all = nullptr;     // [B][emb_total]
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
   int rc = 0;
@@ -327,6 +334,7 @@ struct Fwd {
 
   void gemm(IGemmParams& p) {
     p.zero_page = u->zero_;
+    p.splitk_ws = splitk_ws; p.splitk_ws_floats = splitk_ws_floats;
     if (!dry && !rc) ok(launch_igemm(p, IGemmTune(), s));
   }
   // dense [M][K] x W[N][K]^T
@@ -344,13 +352,21 @@ struct Fwd {
     p.ksize = 3; p.stride = stride; p.up = up; p.w = w; p.M = B * Hout * Wout; p.N = N; p.K = 9 * C; p.splitk = 0;
     return p;
   }
+  // 1x1 conv on split-fp16 operands: A' = [hi | lo | hi], W' = [hi | hi | lo] (packed W_SPLIT3) when precise
+  IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch) {
+    IGemmParams p = dense(hi, M, K, w, N, rows_per_batch);
+    if (u->precise_1x1_) {
+      p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K;
+    }
+    return p;
+  }
   void groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
-                 float* o32, f16* raw) {
+                 float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr) {
     GroupNormParams g;
     g.x0 = x0.p; g.c0 = x0.C;
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
     g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
-    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.partial = gn_partial;
+    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.partial = gn_partial;
     if (!dry && !rc) ok(launch_groupnorm(g, s));
   }
 
@@ -361,7 +377,8 @@ struct Fwd {
     const size_t mark = scratch.off;
     f16* a = S<f16>((size_t)M * Cin);
     f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
-    groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw);
+    f16* raw_lo = (Cin != Cout && u->precise_1x1_) ? S<f16>((size_t)M * Cin) : nullptr;
+    groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
     float* h = S<float>((size_t)M * Cout);
     {
       IGemmParams p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
@@ -375,7 +392,7 @@ struct Fwd {
     Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
     const float* residual = x0.p;
     if (Cin != Cout) {
-      IGemmParams p = dense(raw, M, Cin, L.w16[2], Cout, H * W);
+      IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W);
       p.bias = L.f32[6]; p.out_f32 = out.p; p.ldo = Cout;
       gemm(p);
       residual = out.p;
@@ -411,10 +428,11 @@ struct Fwd {
     const float scale = 1.0f / sqrtf((float)L.dh);
     const size_t mark = scratch.off;
     f16* xn = S<f16>((size_t)M * C);
-    groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr);
+    f16* xn_lo = u->precise_1x1_ ? S<f16>((size_t)M * C) : nullptr;
+    groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
     float* t = S<float>((size_t)M * C);
     {
-      IGemmParams p = dense(xn, M, C, L.w16[0], C, N);
+      IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N);
       p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
       gemm(p);
     }
@@ -473,10 +491,10 @@ struct Fwd {
         gemm(p);
       }
     }
-    if (!dry && !rc) ok(launch_cast_f16(t, ln, (int64_t)M * C, s));
+    if (!dry && !rc) ok(launch_cast_f16(t, ln, xn_lo, (int64_t)M * C, s));
     Act out; out.p = P<float>((size_t)M * C); out.C = C; out.H = H; out.W = W;
     {
-      IGemmParams p = dense(ln, M, C, L.w16[1], C, N);
+      IGemmParams p = dense1x1(ln, xn_lo, M, C, L.w16[1], C, N);
       p.bias = L.f32[3]; p.residual = x.p; p.ldr = C; p.out_f32 = out.p; p.ldo = C;
       gemm(p);
     }
@@ -496,7 +514,7 @@ struct Fwd {
     const int Hout = up ? 2 * Hin : (Hin - 1) / 2 + 1, Wout = up ? 2 * Win : (Win - 1) / 2 + 1;
     const size_t mark = scratch.off;
     f16* x16 = S<f16>((size_t)B * Hin * Win * C);
-    if (!dry && !rc) ok(launch_cast_f16(x.p, x16, (int64_t)B * Hin * Win * C, s));
+    if (!dry && !rc) ok(launch_cast_f16(x.p, x16, nullptr, (int64_t)B * Hin * Win * C, s));
     Act out; out.p = P<float>((size_t)B * Hout * Wout * C); out.C = L.cout; out.H = Hout; out.W = Wout;
     IGemmParams p = conv3(x16, C, Hin, Win, Hout, Wout, up ? 1 : 2, up ? 1 : 0, L.w16[0], L.cout);
     p.bias = L.f32[0]; p.out_f32 = out.p; p.ldo = L.cout;
@@ -565,10 +583,12 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     }
     const int mc = cfg_.model_channels;
     f.gn_partial = f.P<float>(gn_partial_floats(B, H * W));
+    f.splitk_ws_floats = (int64_t)12 << 20;            // 48 MB of fp32 slabs (largest user: 8 x 512 x 1280)
+    f.splitk_ws = f.P<float>((size_t)f.splitk_ws_floats);
     f16* ctx16 = f.P<f16>((size_t)B * Lctx * cfg_.context_dim);
     const bool have_ctx = (ctx != nullptr) || d;
     if (have_ctx) {
-      if (!d) { int r = launch_cast_f16(ctx, ctx16, (int64_t)B * Lctx * cfg_.context_dim, stream); if (r) return r; }
+      if (!d) { int r = launch_cast_f16(ctx, ctx16, nullptr, (int64_t)B * Lctx * cfg_.context_dim, stream); if (r) return r; }
       f.ctx16 = ctx16;
     } else {
       SDMI_CHECK(ctx_valid_, "ctx == NULL but no cached context for this (B, Lctx); call sdmi_unet_cache_context first");

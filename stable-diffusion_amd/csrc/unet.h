@@ -10,7 +10,7 @@
 namespace sdmi {
 
 enum LayerKind { L_CONV_IN, L_RES, L_ATTN, L_DOWN, L_UP };
-enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B };
+enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B, W_SPLIT3 };
 
 struct TBlock {   // BasicTransformerBlock (ldm/modules/attention.py:196-215)
   f16* wqkv = nullptr;   // [3C][C]   attn1 to_q | to_k | to_v
@@ -61,6 +61,9 @@ class UNet {
   sdmi_unet_cfg cfg_{};
   int te_ = 0, emb_total_ = 0, n_attn_ = 0;
   f16* zero_ = nullptr;
+  // 1x1 convs on the residual stream (skip_connection, proj_in, proj_out) run as 3-pass split-fp16 GEMMs
+  // (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): ~22-bit operands for 5 % of the FLOPs (DESIGN.md "precision")
+  bool precise_1x1_ = true;
 
  private:
   friend struct Fwd;

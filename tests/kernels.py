@@ -27,13 +27,29 @@ def pack_geglu(w, b):
     return wd, bd
 
 
-def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, bias=None, rowvec=None, residual=None,
-          out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None):
+def pack_split3(w):
+    N, K_ = w.shape
+    dst = torch.empty((N, 3 * K_), dtype=torch.float16, device=w.device)
+    _lib.check(_lib.load().sdmi_k_pack_split3(w.contiguous().data_ptr(), dst.data_ptr(), N, K_, _s()))
+    return dst
+
+
+def cast_f16(x, want_lo=False):
+    hi = torch.empty(x.shape, dtype=torch.float16, device=x.device)
+    lo = torch.empty_like(hi) if want_lo else None
+    _lib.check(_lib.load().sdmi_k_cast_f16(x.data_ptr(), hi.data_ptr(), _lib.ptr(lo), x.numel(), _s()))
+    return hi, lo
+
+
+def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
+          residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
     d = _lib.IGemmDesc()
     d.a0 = a0.data_ptr(); d.c0 = a0.shape[1]; d.lda0 = a0.stride(0)
     if a1 is not None:
         d.a1 = a1.data_ptr(); d.c1 = a1.shape[1]; d.lda1 = a1.stride(0)
+    if a2 is not None:
+        d.a2 = a2.data_ptr(); d.c2 = a2.shape[1]; d.lda2 = a2.stride(0)
     d.B, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.up = B, Hin, Win, Hout, Wout, ksize, stride, up
     d.w = w.data_ptr(); d.N = N; d.mode = mode
     d.bias = _lib.ptr(bias)
@@ -49,6 +65,11 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, b
             d.seg_dst[i] = t.data_ptr(); d.seg_kind[i] = kind
         d.heads, d.dh, d.ntok, d.ntok_pad, d.segC = heads['heads'], heads['dh'], heads['ntok'], heads['ntok_pad'], heads['segC']
     d.splitk, d.tile, d.dma = splitk, tile, dma
+    ws = None
+    if splitk != 1:
+        M = B * Hout * Wout
+        ws = torch.empty((16 * M * N,), dtype=torch.float32, device=a0.device)
+        d.splitk_ws = ws.data_ptr(); d.splitk_ws_floats = ws.numel()
     _lib.check(_lib.load().sdmi_k_igemm(C.byref(d), _s()))
 
 
@@ -70,12 +91,14 @@ def groupnorm(x0, x1, gamma, beta, eps, silu, want=('f16',)):
     o16 = torch.empty((B, HW, C_), dtype=torch.float16, device=dev) if 'f16' in want else None
     o32 = torch.empty((B, HW, C_), dtype=torch.float32, device=dev) if 'f32' in want else None
     raw = torch.empty((B, HW, C_), dtype=torch.float16, device=dev) if 'raw' in want else None
+    olo = torch.empty((B, HW, C_), dtype=torch.float16, device=dev) if 'lo' in want else None
+    rlo = torch.empty((B, HW, C_), dtype=torch.float16, device=dev) if 'raw_lo' in want else None
     n = _lib.load().sdmi_k_groupnorm_ws_floats(B, HW)
     ws = torch.empty((n,), dtype=torch.float32, device=dev)
     _lib.check(_lib.load().sdmi_k_groupnorm(x0.data_ptr(), _lib.ptr(x1), c0, c1, B, HW, gamma.data_ptr(),
                                             beta.data_ptr(), float(eps), int(silu), _lib.ptr(o16), _lib.ptr(o32),
-                                            _lib.ptr(raw), ws.data_ptr(), n, _s()))
-    return dict(f16=o16, f32=o32, raw=raw)
+                                            _lib.ptr(raw), _lib.ptr(olo), _lib.ptr(rlo), ws.data_ptr(), n, _s()))
+    return dict(f16=o16, f32=o32, raw=raw, lo=olo, raw_lo=rlo)
 
 
 def layernorm(x, gamma, beta, eps=1e-5):

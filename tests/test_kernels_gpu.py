@@ -92,9 +92,38 @@ def test_igemm_splitk_inplace_residual(splitk, tile):
     ref = _nhwc(_conv_ref(a, None, w, B, H, W, 3, 1, 0)) + bias[None] + resid
     wp = K.pack_conv_weight(w.float().to(DEV))
     out = resid.clone().to(DEV)              # in place: out is also the residual (ResBlock skip path)
-    K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV), residual=out, out_f32=out, splitk=splitk, tile=tile)
+    out16 = torch.empty((B * H * W, N), dtype=torch.float16, device=DEV)
+    K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV), residual=out, out_f32=out, out_f16=out16,
+            splitk=splitk, tile=tile)
     torch.cuda.synchronize()
     assert K.report(f'igemm splitk{splitk} tile{tile}', out, ref, 2e-4) < 2e-4
+    assert K.report(f'igemm splitk{splitk} tile{tile} f16', out16, ref, 6e-3) < 6e-3
+    # split-K sums its slabs in a fixed order: bit-identical on a second run
+    out2 = resid.clone().to(DEV)
+    K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV), residual=out2, out_f32=out2, splitk=splitk, tile=tile)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
+def test_igemm_split_fp16_1x1():
+    """3-pass split-fp16 1x1 conv (a_hi w_hi + a_lo w_hi + a_hi w_lo): fp32 operands to ~2^-22."""
+    g = _g(9)
+    M, Kd, N = 300, 320, 192
+    x = torch.randn(M, Kd, generator=g) * 2.0
+    w = torch.randn(N, Kd, generator=g) / math.sqrt(Kd)
+    ref = (x.double() @ w.double().t()).float()
+    hi, lo = K.cast_f16(x.to(DEV), want_lo=True)
+    assert K.report('cast hi', hi, x, 2e-3) < 2e-3
+    assert K.report('cast hi+lo', hi.float() + lo.float(), x.to(DEV), 2e-6) < 2e-6
+    wp = K.pack_split3(w.to(DEV))
+    out = torch.empty((M, N), device=DEV)
+    K.igemm(hi, wp, N, 1, M, 1, M, 1, a1=lo, a2=hi, out_f32=out)
+    torch.cuda.synchronize()
+    err3 = K.report('igemm split3', out, ref, 2e-5)
+    out1 = torch.empty((M, N), device=DEV)
+    K.igemm(hi, w.half().to(DEV).contiguous(), N, 1, M, 1, M, 1, out_f32=out1)
+    err1 = K.report('igemm plain fp16 operands (for comparison)', out1, ref, 1e-2)
+    assert err3 < 2e-5 and err3 < err1 / 20
 
 
 def test_igemm_geglu():
@@ -207,11 +236,13 @@ def test_groupnorm(c0, c1, HW, silu, eps):
         ref = F.silu(ref)
     ref = ref.reshape(B, C, HW).permute(0, 2, 1)
     o = K.groupnorm(x0.to(DEV), None if x1 is None else x1.to(DEV), gamma.to(DEV), beta.to(DEV), eps, silu,
-                    want=('f16', 'f32', 'raw'))
+                    want=('f16', 'f32', 'raw', 'lo', 'raw_lo'))
     torch.cuda.synchronize()
     assert K.report('groupnorm f32', o['f32'], ref, 2e-5) < 2e-5
     assert K.report('groupnorm f16', o['f16'], ref, 4e-3) < 4e-3
     assert K.report('groupnorm raw', o['raw'], x, 4e-3) < 4e-3
+    assert K.report('groupnorm hi+lo', o['f16'].float() + o['lo'].float(), o['f32'], 4e-6) < 4e-6
+    assert K.report('groupnorm raw hi+lo', o['raw'].float() + o['raw_lo'].float(), x, 4e-6) < 4e-6
 
 
 @pytest.mark.parametrize('M,C', [(8192, 320), (512, 1280), (7, 64), (100, 640)])
