@@ -32,9 +32,26 @@ constexpr int BK = 64;
 
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA>
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {   // counted wait: the immediate must be a literal
+  static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24, "add the literal");
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+}
+
+// NS = LDS pipeline depth.  DMA path: NS-1 k-tiles are in flight across the (raw) barrier, retired by a counted
+// s_waitcnt vmcnt(N); the global->LDS latency (~1 us under load) is several k-tiles of MFMA work, so NS = 2 leaves
+// every block waiting on its single outstanding tile.
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA, int NS>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGemmParams p, const int tiles_m,
                                                                        const int tiles_n, const int kt_per_split) {
+  static_assert(DMA || NS == 2, "the register-staged path is double buffered");
   constexpr int NT = WARPS_M * WARPS_N * 64;
   constexpr int RPP = NT / 8;  // rows per load pass (8 chunks of 16 B per 128-B row)
   constexpr int A_PASSES = BM / RPP;
@@ -45,7 +62,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   static_assert(A_PASSES >= 1 && B_PASSES >= 1 && TM >= 1 && TN >= 1, "tile/wave shape");
   static_assert(RPP % 16 == 0, "swizzle assumes pass offset keeps row bits 1..3");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE_BYTES];
 
   // ---- XCD-aware tile assignment (dispatcher places block b on XCD b % 8; speed only) ----------------
   const int nblk = gridDim.x;
@@ -100,7 +117,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   f16x8 regA[DMA ? 1 : A_PASSES], regB[DMA ? 1 : B_PASSES];
 
-  auto issue_loads = [&](int kt, int stage) {
+  auto issue_loads = [&](int kt_req, int stage) {
+    const bool live = kt_req < kt_end;            // past the end: dummy loads from the zero page
+    const int kt = live ? kt_req : kt_begin;
     const int k0 = kt * BK;
     const int tap = k0 / Cin;
     const int cin0 = k0 - tap * Cin;
@@ -115,7 +134,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
       const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
-      const bool ok = (a_pb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
+      const bool ok = live && (a_pb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
       const int sy = p.up ? (iy >> 1) : iy, sx = p.up ? (ix >> 1) : ix;
       const f16* g = ok ? (src + (size_t)(a_pb[i] + sy * p.Win + sx) * ld + coff + gch * 8) : p.zero_page;
       if constexpr (DMA) {
@@ -128,7 +147,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     }
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      const f16* g = b_ptr[i] ? (b_ptr[i] + k0) : p.zero_page;
+      const f16* g = (live && b_ptr[i]) ? (b_ptr[i] + k0) : p.zero_page;
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                          (__attribute__((address_space(3))) void*)(Bs + (i * RPP + wave * 8) * 128), 16,
@@ -161,16 +180,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  issue_loads(kt_begin, 0);
-  commit_regs(0);
-  for (int kt = kt_begin; kt < kt_end; ++kt) {
-    const int cur = (kt - kt_begin) & 1;
-    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const bool more = (kt + 1 < kt_end);
-    if (more) issue_loads(kt + 1, cur ^ 1);
-    const unsigned char* As = smem + cur * STAGE_BYTES + (wm * WTM + l31) * 128;
-    const unsigned char* Bs = smem + cur * STAGE_BYTES + BM * 128 + (wn * WTN + l31) * 128;
+  auto compute = [&](int stage) {
+    const unsigned char* As = smem + stage * STAGE_BYTES + (wm * WTM + l31) * 128;
+    const unsigned char* Bs = smem + stage * STAGE_BYTES + BM * 128 + (wn * WTN + l31) * 128;
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       const int coff = (((ks * 2 + lg) ^ rsw) << 4);
@@ -184,7 +196,33 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
-    if (more) commit_regs(cur ^ 1);
+  };
+
+  if constexpr (DMA) {
+    constexpr int LPT = A_PASSES + B_PASSES;       // DMA instructions per thread per k-tile
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_loads(kt_begin + s, s);
+    int cur = 0, nxt = NS - 1;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      wait_vmcnt<LPT*(NS - 2)>();                  // this wave's share of tile kt has landed
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody's; stage nxt is free again
+      issue_loads(kt + NS - 1, nxt);
+      compute(cur);
+      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+    wait_vmcnt<0>();
+  } else {
+    issue_loads(kt_begin, 0);
+    commit_regs(0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const int cur = (kt - kt_begin) & 1;
+      __syncthreads();
+      const bool more = (kt + 1 < kt_end);
+      if (more) issue_loads(kt + 1, cur ^ 1);
+      compute(cur);
+      if (more) commit_regs(cur ^ 1);
+    }
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
@@ -279,8 +317,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
   const int n = (int)(idx - (int64_t)m * nq) * 4;
   const size_t slab_sz = (size_t)p.M * p.N;
   const float* src = p.splitk_ws + (size_t)m * p.N + n;
-  f32x4 v = *(const f32x4*)src;
-  for (int s = 1; s < nsplit; ++s) v += *(const f32x4*)(src + s * slab_sz);
+  f32x4 part[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0, 0, 0, 0};
+  f32x4 v = part[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s) v += part[s];       // fixed order; absent splits add +0
   if (p.bias) v += *(const f32x4*)(p.bias + n);
   if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / (p.Hout * p.Wout)) * p.ld_rowvec + n);
   if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
@@ -288,7 +330,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
   if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
 }
 
-template <int BM, int BN, int WARPS_M, int WARPS_N>
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
   const int nkt = p.K / BK;
@@ -297,7 +339,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   IGemmParams q = p;
   q.splitk = nsplit;
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
-  static const std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN);
+  static const std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "s" + std::to_string(NS);
   const double src_pix = (double)p.B * p.Hin * p.Win;
   const double out_b = (p.out_f32 ? 4.0 : 0.0) + ((p.out_f16 || p.mode != EPI_PLAIN) ? 2.0 : 0.0);
   const double n_out = p.mode == EPI_GEGLU ? p.N / 2.0 : (double)p.N;
@@ -306,10 +348,10 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream);
   if (dma)
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true>), grid, block, 0, stream, q, tiles_m, tiles_n,
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS>), grid, block, 0, stream, q, tiles_m, tiles_n,
                        kt_per_split);
   else
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false>), grid, block, 0, stream, q, tiles_m, tiles_n,
+    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2>), grid, block, 0, stream, q, tiles_m, tiles_n,
                        kt_per_split);
   SDMI_HIP_OK(hipGetLastError());
   if (nsplit > 1) {
@@ -346,7 +388,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   static const int env_tile = env_int("SDMI_IGEMM_TILE", -1);
   const bool dma = (tune.dma >= 0 ? tune.dma : env_dma) != 0;
   int tile = tune.tile >= 0 ? tune.tile : env_tile;
-  if (p.mode == EPI_GEGLU) tile = 0;
+  if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3 || tile == 6)) tile = 0;   // GEGLU pairs 32-col tiles inside a wave
   if (tile < 0) {
     const long b0 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
     const long b1 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
@@ -354,7 +396,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     else if (b1 >= 224) tile = 1;
     else tile = 2;
   }
-  const int BMs[3] = {128, 128, 64}, BNs[3] = {128, 64, 64};
+  const int BMs[7] = {128, 128, 64, 128, 128, 64, 256}, BNs[7] = {128, 64, 64, 128, 64, 64, 128};
   int splitk = p.splitk;
   const int nkt = p.K / BK;
   static const int env_split = env_int("SDMI_SPLITK", -1);     // 1 disables split-K everywhere
@@ -374,10 +416,14 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     SDMI_CHECK(can_split, "split-K needs plain mode, a slab workspace and N / ldo / ldr multiples of 4");
     SDMI_CHECK((int64_t)splitk * p.M * p.N <= p.splitk_ws_floats, "split-K workspace too small");
   }
-  switch (tile) {
-    case 0: return launch_cfg<128, 128, 2, 2>(p, dma, splitk, stream);
-    case 1: return launch_cfg<128, 64, 2, 2>(p, dma, splitk, stream);
-    case 2: return launch_cfg<64, 64, 2, 2>(p, dma, splitk, stream);
+  switch (tile) {            // tile ids: see include/sdmi.h (sdmi_igemm_desc.tile)
+    case 0: return launch_cfg<128, 128, 2, 2, 3>(p, dma, splitk, stream);
+    case 1: return launch_cfg<128, 64, 2, 2, 3>(p, dma, splitk, stream);
+    case 2: return launch_cfg<64, 64, 2, 2, 4>(p, dma, splitk, stream);
+    case 3: return launch_cfg<128, 128, 2, 2, 2>(p, dma, splitk, stream);
+    case 4: return launch_cfg<128, 64, 2, 2, 2>(p, dma, splitk, stream);
+    case 5: return launch_cfg<64, 64, 2, 2, 2>(p, dma, splitk, stream);
+    case 6: return launch_cfg<256, 128, 4, 2, 2>(p, dma, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }

@@ -53,18 +53,24 @@ __global__ void __launch_bounds__(128) gn_stats_kernel(GroupNormParams p, int nc
   }
 }
 
-// stats[b][g] = {mean, rstd}: 8 threads per group sum the chunk partials (fp64), fixed order
-__global__ void __launch_bounds__(256) gn_finalize_kernel(GroupNormParams p, int nchunk, float* stats) {
+// stats[b][g] = {mean, rstd}: 32 lanes per group sum the chunk partials (fp64), fixed order, loads batched by 4
+__global__ void __launch_bounds__(1024) gn_finalize_kernel(GroupNormParams p, int nchunk, float* stats) {
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int g = tid >> 3, sub = tid & 7;
+  const int g = tid >> 5, sub = tid & 31;
   const int C = p.c0 + p.c1;
   double s = 0.0, ss = 0.0;
-  for (int ch = sub; ch < nchunk; ch += 8) {
-    const float* src = p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2;
-    s += (double)src[0]; ss += (double)src[1];
+  for (int ch0 = sub; ch0 < nchunk; ch0 += 128) {
+    float2 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int ch = ch0 + u * 32;
+      v[u] = (ch < nchunk) ? *(const float2*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2) : float2{0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
   }
 #pragma unroll
-  for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
   if (sub == 0) {
     const double n = (double)(C / 32) * (double)p.HW;
     const double mean = s / n;
@@ -179,7 +185,7 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
   float* stats = p.partial + (size_t)p.B * nchunk * 64;
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(128), 0, stream, p, nchunk);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(256), 0, stream, p, nchunk, stats);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(1024), 0, stream, p, nchunk, stats);
   hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, (const float*)stats);
   SDMI_HIP_OK(hipGetLastError());
   return 0;

@@ -51,7 +51,7 @@ def _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up):
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize('tile', [0, 1, 2])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6])
 @pytest.mark.parametrize('dma', [0, 1])
 def test_igemm_conv(case, tile, dma):
     name, B, Hin, Win, c0, c1, N, ksize, stride, up = case
@@ -81,7 +81,7 @@ def test_igemm_conv(case, tile, dma):
 
 
 @pytest.mark.parametrize('splitk', [0, 2, 5])
-@pytest.mark.parametrize('tile', [0, 2])
+@pytest.mark.parametrize('tile', [0, 2, 6])
 def test_igemm_splitk_inplace_residual(splitk, tile):
     g = _g(5)
     B, H, W, C, N = 2, 4, 4, 256, 192
@@ -113,7 +113,7 @@ def test_igemm_split_fp16_1x1():
     w = torch.randn(N, Kd, generator=g) / math.sqrt(Kd)
     ref = (x.double() @ w.double().t()).float()
     hi, lo = K.cast_f16(x.to(DEV), want_lo=True)
-    assert K.report('cast hi', hi, x, 2e-3) < 2e-3
+    assert K.report('cast hi', hi, x, 8e-3) < 8e-3       # |x| up to ~10: one fp16 rounding
     assert K.report('cast hi+lo', hi.float() + lo.float(), x.to(DEV), 2e-6) < 2e-6
     wp = K.pack_split3(w.to(DEV))
     out = torch.empty((M, N), device=DEV)
@@ -137,10 +137,11 @@ def test_igemm_geglu():
     val, gate = y.chunk(2, dim=-1)
     ref = val * F.gelu(gate)
     wp, bp = K.pack_geglu(w.float().to(DEV), b.to(DEV))
-    out = torch.full((M, N // 2), float('nan'), device=DEV, dtype=torch.float16)
-    K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1)
-    torch.cuda.synchronize()
-    assert K.report('igemm geglu', out, ref, 4e-3) < 4e-3
+    for tile in (0, 3, 6):
+        out = torch.full((M, N // 2), float('nan'), device=DEV, dtype=torch.float16)
+        K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1, tile=tile)
+        torch.cuda.synchronize()
+        assert K.report(f'igemm geglu tile{tile}', out, ref, 4e-3) < 4e-3
 
 
 @pytest.mark.parametrize('ntok,d,heads', [(64, 40, 8), (77, 32, 2), (16, 160, 8), (100, 80, 4)])

@@ -131,10 +131,10 @@ def main():
         out32 = torch.empty(M, N, device=DEV)
         out16 = torch.empty(M, max(N, 8), dtype=torch.float16, device=DEV)
         res = {}
-        tiles = [0] if kind == 'geglu' else [0, 1, 2]
+        tiles = [0, 3, 6] if kind == 'geglu' else [0, 1, 2, 3, 4, 5, 6]
         splits = [1] if kind in ('geglu', 'heads') else ([1, 0] if args.quick else [1, 2, 4, 8, 16])
         for tile in tiles:
-            for dma in ([1] if args.quick else [1, 0]):
+            for dma in [1]:
                 for sk in splits:
                     if sk > 1 and (Kd // 64) // sk < 2:
                         continue
@@ -161,8 +161,11 @@ def main():
                         ms = float('inf')
                     res[f't{tile}d{dma}k{sk}'] = ms
         best = min(res, key=res.get)
-        rows.append(dict(kind=kind, count=count, **kw, M=M, Kd=Kd, best=best, ms=res[best], tflops=flops / res[best] / 1e9,
-                         all={k: round(v, 4) for k, v in res.items()}))
+        row = dict(kind=kind, count=count)
+        row.update(kw)
+        row.update(M=M, Kd=Kd, best=best, ms=res[best], tflops=flops / res[best] / 1e9,
+                   all={k: round(v, 4) for k, v in res.items()})
+        rows.append(row)
         total_best += res[best] * count
     rows.sort(key=lambda r: -r['ms'] * r['count'])
     print(f'{"kind":6s} {"cnt":>3s} {"shape":44s} {"best":10s} {"ms":>8s} {"TF/s":>7s} {"tot ms":>7s}')
