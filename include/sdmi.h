@@ -101,8 +101,8 @@ typedef struct sdmi_igemm_desc {
   int32_t heads, dh, ntok, ntok_pad, segC;
   int32_t splitk;                       /* 1 none, 0 auto, >1 forced (plain mode; needs splitk_ws) */
   float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs [splitk][M][N] */
-  int32_t tile;                         /* -1 auto; 0 128x128 3-stage, 1 128x64 3-stage, 2 64x64 4-stage,
-                                           3/4/5 the same tiles double-buffered, 6 256x128 (8 waves) double-buffered */
+  int32_t tile;                         /* -1 auto; 0 128x128, 1 128x64, 2 64x64, 3 256x128 (8 waves) -- double buffered;
+                                           4 128x64, 5 64x64 with a 3-stage LDS-DMA pipeline */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);

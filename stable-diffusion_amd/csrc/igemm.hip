@@ -48,7 +48,7 @@ __device__ __forceinline__ void wait_vmcnt() {   // counted wait: the immediate 
 // NS = LDS pipeline depth.  DMA path: NS-1 k-tiles are in flight across the (raw) barrier, retired by a counted
 // s_waitcnt vmcnt(N); the global->LDS latency (~1 us under load) is several k-tiles of MFMA work, so NS = 2 leaves
 // every block waiting on its single outstanding tile.
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA, int NS>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA, int NS, bool UP>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGemmParams p, const int tiles_m,
                                                                        const int tiles_n, const int kt_per_split) {
   static_assert(DMA || NS == 2, "the register-staged path is double buffered");
@@ -87,74 +87,113 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   const int lrow = tid >> 3;                     // row inside a load pass
   const int gch = cpos ^ ((lrow >> 1) & 7);      // global chunk that lands at (row, cpos)
 
-  // ---- per-row gather metadata ---------------------------------------------------------------------
+  // ---- per-row gather metadata (computed once; the k-loop only adds wave-uniform offsets) -----------------
+  // Row m of the implicit A matrix is output pixel (b, oy, ox).  Tap (ky, kx) of a 3x3 conv reads input pixel
+  // (oy*stride + ky - 1, ox*stride + kx - 1): an offset that is affine in the tap, so per row we keep the element
+  // offset of the centre tap and a 9-bit mask of the taps that fall inside the image.  (UP: nearest-x2 upsampled
+  // input -- the source pixel is ((oy+ky-1)>>1, (ox+kx-1)>>1), not affine, so the three row / column offsets
+  // are tabulated per row instead.)
   const int HWout = p.Hout * p.Wout;
   const int Cin = p.c0 + p.c1 + p.c2;
   const int pad = (p.ksize == 3) ? 1 : 0;
-  const int Hv = p.up ? 2 * p.Hin : p.Hin;
-  const int Wv = p.up ? 2 * p.Win : p.Win;
-  int a_pb[A_PASSES], a_oy[A_PASSES], a_ox[A_PASSES];
+  const int ntap = p.ksize * p.ksize;
+  const int ld = p.lda0;                            // all sources share the row pitch (checked by the launcher)
+  int a_off[A_PASSES]; unsigned a_mask[A_PASSES];
+  int a_ro[UP ? A_PASSES : 1][3], a_co[UP ? A_PASSES : 1][3];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = m0 + i * RPP + lrow;
+    a_off[i] = 0; a_mask[i] = 0;
     if (m < p.M) {
       const int b = m / HWout;
       const int rem = m - b * HWout;
-      const int oy = rem / p.Wout;
-      a_pb[i] = b * p.Hin * p.Win;
-      a_oy[i] = oy * p.stride - pad;
-      a_ox[i] = (rem - oy * p.Wout) * p.stride - pad;
-    } else {
-      a_pb[i] = -1; a_oy[i] = 0; a_ox[i] = 0;
+      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+      const int pb = b * p.Hin * p.Win;
+      if constexpr (UP) {
+        const int Hv = 2 * p.Hin, Wv = 2 * p.Win;
+        unsigned mk = 0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const int iy = oy + d - 1, ix = ox + d - 1;
+          a_ro[i][d] = (pb + (max(iy, 0) >> 1) * p.Win) * ld;
+          a_co[i][d] = (max(ix, 0) >> 1) * ld + gch * 8;
+        }
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+          if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
+      } else {
+        const int cy = oy * p.stride, cx = ox * p.stride;          // centre tap
+        a_off[i] = (pb + cy * p.Win + cx) * ld + gch * 8;
+        unsigned mk = 0;
+        for (int t = 0; t < ntap; ++t) {
+          const int iy = cy + (pad ? t / 3 - 1 : 0), ix = cx + (pad ? t % 3 - 1 : 0);
+          if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mk |= 1u << t;
+        }
+        a_mask[i] = mk;
+      }
     }
   }
-  const f16* b_ptr[B_PASSES];
+  int b_off[B_PASSES];
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
     const int n = n0 + i * RPP + lrow;
-    b_ptr[i] = (n < p.N) ? (p.w + (size_t)n * p.K + gch * 8) : nullptr;
+    b_off[i] = (n < p.N) ? (n * p.K + gch * 8) : -1;
   }
 
   f16x8 regA[DMA ? 1 : A_PASSES], regB[DMA ? 1 : B_PASSES];
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably scalar -> LDS-DMA bases stay in SGPRs
 
-  auto issue_loads = [&](int kt_req, int stage) {
-    const bool live = kt_req < kt_end;            // past the end: dummy loads from the zero page
-    const int kt = live ? kt_req : kt_begin;
-    const int k0 = kt * BK;
-    const int tap = k0 / Cin;
-    const int cin0 = k0 - tap * Cin;
-    const int ky = (p.ksize == 3) ? tap / 3 : 0;
-    const int kx = (p.ksize == 3) ? tap - ky * 3 : 0;
-    const f16* src; int ld, coff;
-    if (cin0 < p.c0) { src = p.a0; ld = p.lda0; coff = cin0; }
-    else if (cin0 < p.c0 + p.c1) { src = p.a1; ld = p.lda1; coff = cin0 - p.c0; }
-    else { src = p.a2; ld = p.lda2; coff = cin0 - p.c0 - p.c1; }
+  // load cursor (wave-uniform): next k-tile to issue, its tap and first channel
+  int ld_kt = kt_begin;
+  int ld_tap = (kt_begin * BK) / Cin;
+  int ld_cin0 = kt_begin * BK - ld_tap * Cin;
+  int ld_ky = pad ? ld_tap / 3 : 0, ld_kx = pad ? ld_tap - 3 * (ld_tap / 3) : 0;
+
+  auto issue_loads = [&](int stage) {
+    const bool live = ld_kt < kt_end;             // past the end (NS > 2): dummy loads from the zero page
+    const f16* src; int coff;
+    if (ld_cin0 < p.c0) { src = p.a0; coff = ld_cin0; }
+    else if (ld_cin0 < p.c0 + p.c1) { src = p.a1; coff = ld_cin0 - p.c0; }
+    else { src = p.a2; coff = ld_cin0 - p.c0 - p.c1; }
+    const int tapoff = ((ld_ky - pad) * p.Win + (ld_kx - pad)) * ld + coff;     // scalar
+    const unsigned tapbit = live ? (1u << ld_tap) : 0u;
     unsigned char* As = smem + stage * STAGE_BYTES;
     unsigned char* Bs = As + BM * 128;
 #pragma unroll
     for (int i = 0; i < A_PASSES; ++i) {
-      const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
-      const bool ok = live && (a_pb[i] >= 0) && (iy >= 0) && (iy < Hv) && (ix >= 0) && (ix < Wv);
-      const int sy = p.up ? (iy >> 1) : iy, sx = p.up ? (ix >> 1) : ix;
-      const f16* g = ok ? (src + (size_t)(a_pb[i] + sy * p.Win + sx) * ld + coff + gch * 8) : p.zero_page;
+      int off;
+      if constexpr (UP) off = a_ro[i][ld_ky] + a_co[i][ld_kx] + coff;
+      else off = a_off[i] + tapoff;
+      const f16* g = (a_mask[i] & tapbit) ? (src + off) : p.zero_page;
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(As + (i * RPP + wave * 8) * 128), 16,
-                                         0, 0);
+                                         (__attribute__((address_space(3))) void*)(As + (i * RPP + wave_u * 8) * 128),
+                                         16, 0, 0);
       } else {
         regA[i] = *(const f16x8*)g;
       }
     }
+    const f16* wk = p.w + ld_kt * BK;
 #pragma unroll
     for (int i = 0; i < B_PASSES; ++i) {
-      const f16* g = (live && b_ptr[i]) ? (b_ptr[i] + k0) : p.zero_page;
+      const f16* g = (live && b_off[i] >= 0) ? (wk + b_off[i]) : p.zero_page;
       if constexpr (DMA) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(Bs + (i * RPP + wave * 8) * 128), 16,
-                                         0, 0);
+                                         (__attribute__((address_space(3))) void*)(Bs + (i * RPP + wave_u * 8) * 128),
+                                         16, 0, 0);
       } else {
         regB[i] = *(const f16x8*)g;
       }
+    }
+    // advance the cursor
+    ++ld_kt;
+    ld_cin0 += BK;
+    if (ld_cin0 == Cin) {
+      ld_cin0 = 0; ++ld_tap;
+      if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
     }
   };
   auto commit_regs = [&](int stage) {   // register-staged path: write the prefetched tile into LDS
@@ -201,25 +240,25 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   if constexpr (DMA) {
     constexpr int LPT = A_PASSES + B_PASSES;       // DMA instructions per thread per k-tile
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_loads(kt_begin + s, s);
+    for (int s = 0; s < NS - 1; ++s) issue_loads(s);
     int cur = 0, nxt = NS - 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       wait_vmcnt<LPT*(NS - 2)>();                  // this wave's share of tile kt has landed
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody's; stage nxt is free again
-      issue_loads(kt + NS - 1, nxt);
+      issue_loads(nxt);
       compute(cur);
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();
   } else {
-    issue_loads(kt_begin, 0);
+    issue_loads(0);
     commit_regs(0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       const int cur = (kt - kt_begin) & 1;
       __syncthreads();
       const bool more = (kt + 1 < kt_end);
-      if (more) issue_loads(kt + 1, cur ^ 1);
+      if (more) issue_loads(cur ^ 1);
       compute(cur);
       if (more) commit_regs(cur ^ 1);
     }
@@ -347,12 +386,13 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
                src_pix * (p.c0 + p.c1) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * n_out * out_b +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream);
-  if (dma)
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS>), grid, block, 0, stream, q, tiles_m, tiles_n,
-                       kt_per_split);
-  else
-    hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2>), grid, block, 0, stream, q, tiles_m, tiles_n,
-                       kt_per_split);
+  if (p.up) {
+    if (dma) hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, true>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, true>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+  } else {
+    if (dma) hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, false>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, false>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+  }
   SDMI_HIP_OK(hipGetLastError());
   if (nsplit > 1) {
     const int64_t total = (int64_t)p.M * (p.N / 4);
@@ -381,6 +421,10 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   SDMI_CHECK(p.M == p.B * p.Hout * p.Wout, "M != B * Hout * Wout");
   SDMI_CHECK(p.c1 == 0 || p.a1 != nullptr, "second A source missing");
   SDMI_CHECK(p.c2 == 0 || (p.a2 != nullptr && p.lda2 % 8 == 0), "third A source missing");
+  SDMI_CHECK((p.c1 == 0 || p.lda1 == p.lda0) && (p.c2 == 0 || p.lda2 == p.lda0), "all A sources must share one row pitch");
+  SDMI_CHECK(!p.up || (p.ksize == 3 && p.stride == 1), "upsample folding needs a 3x3 stride-1 conv");
+  SDMI_CHECK((int64_t)p.B * p.Hin * p.Win * p.lda0 < (int64_t)1 << 31 && (int64_t)p.N * p.K < (int64_t)1 << 31,
+             "tensor too large for 32-bit element offsets");
   if (p.mode == EPI_GEGLU) SDMI_CHECK(p.N % 64 == 0 && p.out_f16 != nullptr, "GEGLU needs N % 64 == 0 and an fp16 output");
   if (p.mode == EPI_HEADS) SDMI_CHECK(p.segC > 0 && p.dh > 0 && p.N % p.segC == 0 && p.N / p.segC <= 3, "bad head scatter");
 
@@ -388,7 +432,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   static const int env_tile = env_int("SDMI_IGEMM_TILE", -1);
   const bool dma = (tune.dma >= 0 ? tune.dma : env_dma) != 0;
   int tile = tune.tile >= 0 ? tune.tile : env_tile;
-  if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3 || tile == 6)) tile = 0;   // GEGLU pairs 32-col tiles inside a wave
+  if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3)) tile = 0;   // GEGLU pairs 32-col tiles inside a wave
   if (tile < 0) {
     const long b0 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
     const long b1 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
@@ -396,7 +440,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     else if (b1 >= 224) tile = 1;
     else tile = 2;
   }
-  const int BMs[7] = {128, 128, 64, 128, 128, 64, 256}, BNs[7] = {128, 64, 64, 128, 64, 64, 128};
+  const int BMs[6] = {128, 128, 64, 256, 128, 64}, BNs[6] = {128, 64, 64, 128, 64, 64};
   int splitk = p.splitk;
   const int nkt = p.K / BK;
   static const int env_split = env_int("SDMI_SPLITK", -1);     // 1 disables split-K everywhere
@@ -417,13 +461,12 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     SDMI_CHECK((int64_t)splitk * p.M * p.N <= p.splitk_ws_floats, "split-K workspace too small");
   }
   switch (tile) {            // tile ids: see include/sdmi.h (sdmi_igemm_desc.tile)
-    case 0: return launch_cfg<128, 128, 2, 2, 3>(p, dma, splitk, stream);
-    case 1: return launch_cfg<128, 64, 2, 2, 3>(p, dma, splitk, stream);
-    case 2: return launch_cfg<64, 64, 2, 2, 4>(p, dma, splitk, stream);
-    case 3: return launch_cfg<128, 128, 2, 2, 2>(p, dma, splitk, stream);
-    case 4: return launch_cfg<128, 64, 2, 2, 2>(p, dma, splitk, stream);
-    case 5: return launch_cfg<64, 64, 2, 2, 2>(p, dma, splitk, stream);
-    case 6: return launch_cfg<256, 128, 4, 2, 2>(p, dma, splitk, stream);
+    case 0: return launch_cfg<128, 128, 2, 2, 2>(p, dma, splitk, stream);
+    case 1: return launch_cfg<128, 64, 2, 2, 2>(p, dma, splitk, stream);
+    case 2: return launch_cfg<64, 64, 2, 2, 2>(p, dma, splitk, stream);
+    case 3: return launch_cfg<256, 128, 4, 2, 2>(p, dma, splitk, stream);
+    case 4: return launch_cfg<128, 64, 2, 2, 3>(p, dma, splitk, stream);
+    case 5: return launch_cfg<64, 64, 2, 2, 3>(p, dma, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }

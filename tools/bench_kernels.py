@@ -131,7 +131,7 @@ def main():
         out32 = torch.empty(M, N, device=DEV)
         out16 = torch.empty(M, max(N, 8), dtype=torch.float16, device=DEV)
         res = {}
-        tiles = [0, 3, 6] if kind == 'geglu' else [0, 1, 2, 3, 4, 5, 6]
+        tiles = [0, 3] if kind == 'geglu' else [0, 1, 2, 3, 4, 5]
         splits = [1] if kind in ('geglu', 'heads') else ([1, 0] if args.quick else [1, 2, 4, 8, 16])
         for tile in tiles:
             for dma in [1]:
