@@ -67,6 +67,7 @@ struct IGemmParams {
   int splitk = 1;                                      // 1 none, 0 auto, >1 forced
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
+  int debug = 0;                                       // perf ablation only (SDMI_IGEMM_ABLATE): 1 skip k-loop loads, 2 skip MFMA work
 };
 
 struct IGemmTune {        // runtime knobs (tests sweep them; the executor picks by heuristic)

@@ -26,6 +26,11 @@
 
 namespace sdmi {
 
+static int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v ? atoi(v) : dflt;
+}
+
 namespace {
 
 constexpr int BK = 64;
@@ -245,8 +250,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     for (int kt = kt_begin; kt < kt_end; ++kt) {
       wait_vmcnt<LPT*(NS - 2)>();                  // this wave's share of tile kt has landed
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody's; stage nxt is free again
-      issue_loads(nxt);
-      compute(cur);
+      if (!(p.debug & 1)) issue_loads(nxt);
+      if (!(p.debug & 2)) compute(cur);
       cur = (cur + 1 == NS) ? 0 : cur + 1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
@@ -377,6 +382,8 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int nsplit = cdiv(nkt, kt_per_split);
   IGemmParams q = p;
   q.splitk = nsplit;
+  static const int ablate = env_int("SDMI_IGEMM_ABLATE", 0);
+  q.debug = ablate;
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
   static const std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "s" + std::to_string(NS);
   const double src_pix = (double)p.B * p.Hin * p.Win;
@@ -405,11 +412,6 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
 
 }  // namespace
 
-static int env_int(const char* name, int dflt) {
-  const char* v = getenv(name);
-  return v ? atoi(v) : dflt;
-}
-
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream) {
   SDMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SDMI_CHECK(p.ksize == 1 || p.ksize == 3, "ksize must be 1 or 3");
@@ -433,12 +435,13 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   const bool dma = (tune.dma >= 0 ? tune.dma : env_dma) != 0;
   int tile = tune.tile >= 0 ? tune.tile : env_tile;
   if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3)) tile = 0;   // GEGLU pairs 32-col tiles inside a wave
+  // Tile / split-K choice, from the per-shape sweep of tools/bench_kernels.py on MI355X (profiles/kbench_r01.txt):
+  // every shape of this UNet is bound by L2->LDS bytes in flight, so the many-block 64x64 tile wins except for
+  // the few >= 25 GFLOP convs, where the 256x128 tile (fewest bytes per FLOP) is ~10 % faster.
+  const double gflop = 2.0 * p.M * (double)p.N * p.K * 1e-9;
   if (tile < 0) {
-    const long b0 = (long)cdiv(p.M, 128) * cdiv(p.N, 128);
-    const long b1 = (long)cdiv(p.M, 128) * cdiv(p.N, 64);
-    if (b0 >= 224) tile = 0;
-    else if (b1 >= 224) tile = 1;
-    else tile = 2;
+    if (p.mode == EPI_HEADS) tile = 2;
+    else tile = (gflop >= 25.0) ? 3 : 2;
   }
   const int BMs[6] = {128, 128, 64, 256, 128, 64}, BNs[6] = {128, 64, 64, 128, 64, 64};
   int splitk = p.splitk;
@@ -447,11 +450,12 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   const bool can_split = p.mode == EPI_PLAIN && p.splitk_ws && p.N % 4 == 0 && p.ldo % 4 == 0 &&
                          (p.residual == nullptr || p.ldr % 4 == 0);
   if (env_split >= 0 && splitk == 0) splitk = env_split;
-  if (splitk <= 0) {  // auto: fill the 256 CUs when the tile grid alone cannot, keeping >= 4 k-tiles per split
+  if (splitk <= 0) {  // auto: enough blocks to keep bytes in flight on all 256 CUs, >= 8 k-tiles per split
     splitk = 1;
     if (can_split) {
       const long blocks = (long)cdiv(p.M, BMs[tile]) * cdiv(p.N, BNs[tile]);
-      while (blocks * splitk < 256 && nkt / (splitk * 2) >= 4 && splitk < 16 &&
+      const long want = (tile == 3) ? 160 : 512;
+      while (blocks * splitk < want && nkt / (splitk * 2) >= 8 && splitk < 16 &&
              (int64_t)(splitk * 2) * p.M * p.N <= p.splitk_ws_floats)
         splitk *= 2;
     }

@@ -57,8 +57,10 @@ def test_igemm_conv(case, tile, dma):
     name, B, Hin, Win, c0, c1, N, ksize, stride, up = case
     g = _g(hash(name) % 1000)
     Cin = c0 + c1
-    a0 = _rand16((B * Hin * Win, c0), g)
-    a1 = _rand16((B * Hin * Win, c1), g) if c1 else None
+    # two channel-concatenated sources share one row pitch (they are column slices of one buffer, as in the executor)
+    big = _rand16((B * Hin * Win, Cin), g)
+    a0 = big[:, :c0]
+    a1 = big[:, c0:] if c1 else None
     w = _rand16((N, Cin, ksize, ksize), g, 1.0 / math.sqrt(Cin * ksize * ksize))
     ref = _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up)          # [B,N,Hout,Wout] fp32 (CPU)
     Hout, Wout = ref.shape[2], ref.shape[3]
@@ -70,7 +72,8 @@ def test_igemm_conv(case, tile, dma):
     wp = K.pack_conv_weight(w.float().to(DEV))
     out32 = torch.full((M, N), float('nan'), device=DEV)
     out16 = torch.full((M, N), float('nan'), device=DEV, dtype=torch.float16)
-    K.igemm(a0.to(DEV), wp, N, B, Hin, Win, Hout, Wout, ksize, stride, up, a1=None if a1 is None else a1.to(DEV),
+    big_d = big.to(DEV)
+    K.igemm(big_d[:, :c0], wp, N, B, Hin, Win, Hout, Wout, ksize, stride, up, a1=big_d[:, c0:] if c1 else None,
             bias=bias.to(DEV), rowvec=rowvec.to(DEV), residual=resid.to(DEV), out_f32=out32, out_f16=out16,
             tile=tile, dma=dma)
     torch.cuda.synchronize()
