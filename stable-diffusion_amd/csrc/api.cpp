@@ -115,6 +115,7 @@ int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, in
   AttnParams a;
   a.q = (const f16*)q; a.k = (const f16*)k; a.vt = (const f16*)vt; a.out = (f16*)out;
   a.BH = BH; a.heads = heads; a.nq = nq; a.nkv = nkv; a.nkv_pad = nkv_pad; a.d = d; a.scale = scale;
+  if (const char* e = getenv("SDMI_ATTN_NW")) a.nw = atoi(e);     // test / tuning knob
   return launch_attention(a, (hipStream_t)stream);
 }
 int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { return gn_partial_floats(B, HW); }

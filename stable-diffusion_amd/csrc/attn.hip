@@ -219,12 +219,13 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
 
 template <int D>
 int launch_d(const AttnParams& p, hipStream_t stream) {
-  const long bh = p.BH;
-  int nw = 8;
-  if ((long)cdiv(p.nq, 256) * bh < 256) nw = 4;
-  if ((long)cdiv(p.nq, 128) * bh < 256) nw = 2;
-  static const char* env = getenv("SDMI_ATTN_NW");
-  if (env) nw = atoi(env);
+  // Few, latency-bound workgroups (short sequences at the 16x16 / 8x8 levels): use as many waves as there are
+  // 32-query slices so the K/V tile loads are spread over more threads; long sequences: 8 waves share each tile.
+  int nw = p.nw;
+  if (nw <= 0) {
+    const int slices = cdiv(p.nq, 32);
+    nw = slices >= 8 ? 8 : (slices >= 4 ? 4 : 2);
+  }
   dim3 grid(cdiv(p.nq, 32 * nw), p.BH);
   static const std::string pname = std::string("attn_d") + std::to_string(D);
   ProfScope ps(pname.c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);

@@ -85,6 +85,7 @@ struct AttnParams {
   f16* out = nullptr;        // [B][nq][heads*d]  (heads merged, '(b h) n d -> b n (h d)')
   int BH = 0, heads = 0, nq = 0, nkv = 0, nkv_pad = 0, d = 0;
   float scale = 1.f;
+  int nw = 0;                // waves per workgroup (0 = auto): each wave owns 32 queries
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
 

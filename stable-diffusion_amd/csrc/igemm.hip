@@ -326,6 +326,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
       }
     }
   } else {  // EPI_HEADS
+    // lane = output column (seg, head, dd); registers 4q..4q+3 = 4 consecutive rows (tokens)
+    const bool vec4 = (p.ntok % 4 == 0) && (p.ntok_pad % 4 == 0);
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       const int n = nw + j * 32 + l31;
@@ -339,14 +341,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-          if (m >= p.M) continue;
-          const int b = m / p.ntok;
-          const int tok = m - b * p.ntok;
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int mq = mw + i * 32 + 8 * r4 + 4 * lg;       // first of 4 consecutive rows (multiple of 4)
+          if (mq >= p.M) continue;
+          const int b = mq / p.ntok;
+          const int tok = mq - b * p.ntok;
           const size_t bh = (size_t)b * p.heads + head;
-          const size_t off = kind == 0 ? ((bh * p.ntok + tok) * p.dh + dd) : ((bh * p.dh + dd) * p.ntok_pad + tok);
-          dst[off] = (f16)acc[i][j][r];
+          if (kind == 1 && vec4 && mq + 3 < p.M) {
+            *(f16x4*)(dst + (bh * p.dh + dd) * p.ntok_pad + tok) =
+                f16x4{(f16)acc[i][j][r4 * 4 + 0], (f16)acc[i][j][r4 * 4 + 1], (f16)acc[i][j][r4 * 4 + 2],
+                      (f16)acc[i][j][r4 * 4 + 3]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int m = mq + e;
+              if (m >= p.M) continue;
+              const int b2 = m / p.ntok;
+              const int t2 = m - b2 * p.ntok;
+              const size_t bh2 = (size_t)b2 * p.heads + head;
+              const size_t off = kind == 0 ? ((bh2 * p.ntok + t2) * p.dh + dd) : ((bh2 * p.dh + dd) * p.ntok_pad + t2);
+              dst[off] = (f16)acc[i][j][r4 * 4 + e];
+            }
+          }
         }
     }
   }
@@ -401,6 +417,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
     else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, false>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
   }
   SDMI_HIP_OK(hipGetLastError());
+  ps.end();
   if (nsplit > 1) {
     const int64_t total = (int64_t)p.M * (p.N / 4);
     ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);

@@ -11,7 +11,7 @@
 namespace sdmi {
 namespace {
 
-constexpr int GN_CHUNK = 8;     // pixels per statistics block (fully unrolled: 8 independent loads in flight)
+constexpr int GN_CHUNK = 64;    // pixels per statistics block
 constexpr int GN_MAXC = 2560 * 2;
 
 __device__ __forceinline__ f32x4 load_cat4(const float* x0, const float* x1, int c0, int c1, size_t pix, int c) {
@@ -25,21 +25,23 @@ __device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp
 }
 
 // partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g)
-__global__ void __launch_bounds__(128) gn_stats_kernel(GroupNormParams p, int nchunk) {
+__global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk) {
   __shared__ float csum[GN_MAXC], csq[GN_MAXC];
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int pix0 = chunk * GN_CHUNK;
   const int npix = min(GN_CHUNK, p.HW - pix0);
-  for (int q = tid; q < C / 4; q += 128) {
+  for (int q = tid; q < C / 4; q += 256) {
     const int c = q * 4;
-    f32x4 v[GN_CHUNK];
-#pragma unroll
-    for (int i = 0; i < GN_CHUNK; ++i)
-      v[i] = (i < npix) ? load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + i, c) : f32x4{0, 0, 0, 0};
     f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+    for (int i0 = 0; i0 < npix; i0 += 8) {         // 8 independent loads in flight per thread
+      f32x4 v[8];
 #pragma unroll
-    for (int i = 0; i < GN_CHUNK; ++i) { s += v[i]; ss += v[i] * v[i]; }
+      for (int i = 0; i < 8; ++i)
+        v[i] = (i0 + i < npix) ? load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + i0 + i, c) : f32x4{0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { s += v[i]; ss += v[i] * v[i]; }
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) { csum[c + j] = s[j]; csq[c + j] = ss[j]; }
   }
@@ -53,42 +55,39 @@ __global__ void __launch_bounds__(128) gn_stats_kernel(GroupNormParams p, int nc
   }
 }
 
-// stats[b][g] = {mean, rstd}: 32 lanes per group sum the chunk partials (fp64), fixed order, loads batched by 4
-__global__ void __launch_bounds__(1024) gn_finalize_kernel(GroupNormParams p, int nchunk, float* stats) {
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int g = tid >> 5, sub = tid & 31;
-  const int C = p.c0 + p.c1;
-  double s = 0.0, ss = 0.0;
-  for (int ch0 = sub; ch0 < nchunk; ch0 += 128) {
-    float2 v[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int ch = ch0 + u * 32;
-      v[u] = (ch < nchunk) ? *(const float2*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2) : float2{0.f, 0.f};
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
-  }
-#pragma unroll
-  for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-  if (sub == 0) {
-    const double n = (double)(C / 32) * (double)p.HW;
-    const double mean = s / n;
-    double var = ss / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    stats[(b * 32 + g) * 2 + 0] = (float)mean;
-    stats[(b * 32 + g) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
-  }
-}
-
 constexpr int GN_APPLY_PIX = 8;
 
-__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const float* stats) {
+// normalise (+SiLU); every block first folds the chunk partials of its batch row into {mean, rstd} per group
+// (8 lanes per group, fp64, fixed order) -- cheaper than a third launch
+__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nchunk) {
   __shared__ float s_mean[32], s_rstd[32];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
-  if (tid < 32) { s_mean[tid] = stats[(b * 32 + tid) * 2]; s_rstd[tid] = stats[(b * 32 + tid) * 2 + 1]; }
+  {
+    const int g = tid >> 3, sub = tid & 7;
+    double s = 0.0, ss = 0.0;
+    for (int ch0 = sub; ch0 < nchunk; ch0 += 32) {
+      float2 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int ch = ch0 + u * 8;
+        v[u] = (ch < nchunk) ? *(const float2*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2) : float2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
+    }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if (sub == 0) {
+      const double n = (double)cpg * (double)p.HW;
+      const double mean = s / n;
+      double var = ss / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      s_mean[g] = (float)mean;
+      s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+  }
   __syncthreads();
   const int pix0 = blockIdx.x * GN_APPLY_PIX;
   const int npix = min(GN_APPLY_PIX, p.HW - pix0);
@@ -173,7 +172,7 @@ __global__ void cast_f16_kernel(const float* x, f16* out, f16* out_lo, int64_t n
 
 }  // namespace
 
-int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64 + B * 64; }
+int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64; }
 
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int C = p.c0 + p.c1;
@@ -183,10 +182,8 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int nchunk = cdiv(p.HW, GN_CHUNK);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
-  float* stats = p.partial + (size_t)p.B * nchunk * 64;
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(128), 0, stream, p, nchunk);
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(p.B), dim3(1024), 0, stream, p, nchunk, stats);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, (const float*)stats);
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, nchunk);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

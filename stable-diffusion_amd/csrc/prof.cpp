@@ -15,14 +15,15 @@ std::vector<Rec> g_recs;
 
 bool prof_enabled() { return g_on; }
 
-void prof_record_begin(const char* name, double flops, double bytes, hipStream_t s) {
+int prof_record_begin(const char* name, double flops, double bytes, hipStream_t s) {
   Rec r; r.name = name; r.flops = flops; r.bytes = bytes;
   (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
+  return (int)g_recs.size() - 1;
 }
-void prof_record_end(hipStream_t s) {
-  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s);
+void prof_record_end(int idx, hipStream_t s) {
+  if (idx >= 0 && idx < (int)g_recs.size()) (void)hipEventRecord(g_recs[idx].e1, s);
 }
 
 int prof_begin() {

@@ -8,15 +8,16 @@
 namespace sdmi {
 
 bool prof_enabled();
-void prof_record_begin(const char* name, double flops, double bytes, hipStream_t s);
-void prof_record_end(hipStream_t s);
+int prof_record_begin(const char* name, double flops, double bytes, hipStream_t s);   // returns the record index
+void prof_record_end(int idx, hipStream_t s);
 
 struct ProfScope {
-  hipStream_t s; bool on;
+  hipStream_t s; bool on; int idx = -1;
   ProfScope(const char* name, double flops, double bytes, hipStream_t stream) : s(stream), on(prof_enabled()) {
-    if (on) prof_record_begin(name, flops, bytes, s);
+    if (on) idx = prof_record_begin(name, flops, bytes, s);
   }
-  ~ProfScope() { if (on) prof_record_end(s); }
+  void end() { if (on && idx >= 0) { prof_record_end(idx, s); idx = -1; } }   // close early (before a follow-up launch)
+  ~ProfScope() { end(); }
 };
 
 int prof_begin();

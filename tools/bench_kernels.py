@@ -108,10 +108,13 @@ def main():
             res = {}
             for nw in (2, 4, 8):
                 os.environ['SDMI_ATTN_NW'] = str(nw)
-                # NOTE: the env knob is read once per template instance; only the first value sticks per d.
-                break
-            ms = time_fn(lambda: K.attention(q, k, vt, heads, nkv, d ** -0.5), args.iters)
-            rows.append(dict(kind=kind, count=count, **kw, best='-', ms=ms, tflops=flops / ms / 1e9, all={}))
+                res[f'nw{nw}'] = time_fn(lambda: K.attention(q, k, vt, heads, nkv, d ** -0.5), args.iters)
+            os.environ.pop('SDMI_ATTN_NW')
+            res['auto'] = time_fn(lambda: K.attention(q, k, vt, heads, nkv, d ** -0.5), args.iters)
+            best = min(res, key=res.get)
+            ms = res[best]
+            rows.append(dict(kind=kind, count=count, **kw, best=best, ms=ms, tflops=flops / ms / 1e9,
+                             all={k_: round(v_, 4) for k_, v_ in res.items()}))
             total_best += ms * count
             continue
         if kind == 'conv3':
