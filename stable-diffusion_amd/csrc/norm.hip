@@ -24,32 +24,53 @@ __device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp
   return r;
 }
 
-// partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g)
+// partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g).
+// Threads are laid out as [pixel lane][channel quad] so that (almost) all 256 threads have loads in flight even
+// at C = 320 (80 quads -> 3 pixel lanes); sums are combined through LDS in a fixed order (deterministic).
 __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk) {
   __shared__ float csum[GN_MAXC], csq[GN_MAXC];
+  __shared__ float lsum[3][1024], lsq[3][1024];       // extra pixel lanes (PL <= 4) for C <= 1024
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
+  const int nq = C / 4;
   const int pix0 = chunk * GN_CHUNK;
   const int npix = min(GN_CHUNK, p.HW - pix0);
-  for (int q = tid; q < C / 4; q += 256) {
-    const int c = q * 4;
-    f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
-    for (int i0 = 0; i0 < npix; i0 += 8) {         // 8 independent loads in flight per thread
-      f32x4 v[8];
+  const int PL = (nq <= 256) ? min(4, 256 / nq) : 1;   // pixel lanes
+  const int pl = (nq <= 256) ? tid / nq : 0;
+  const int q0 = (nq <= 256) ? tid - pl * nq : tid;
+  if (pl < PL) {
+    for (int q = q0; q < nq; q += 256) {
+      const int c = q * 4;
+      f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+      for (int i0 = pl; i0 < npix; i0 += 8 * PL) {      // 8 independent loads in flight per thread
+        f32x4 v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i)
-        v[i] = (i0 + i < npix) ? load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + i0 + i, c) : f32x4{0, 0, 0, 0};
+        for (int i = 0; i < 8; ++i) {
+          const int pi = i0 + i * PL;
+          v[i] = (pi < npix) ? load_cat4(p.x0, p.x1, p.c0, p.c1, (size_t)b * p.HW + pix0 + pi, c) : f32x4{0, 0, 0, 0};
+        }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { s += v[i]; ss += v[i] * v[i]; }
+        for (int i = 0; i < 8; ++i) { s += v[i]; ss += v[i] * v[i]; }
+      }
+      if (pl == 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { csum[c + j] = s[j]; csq[c + j] = ss[j]; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { lsum[pl - 1][c + j] = s[j]; lsq[pl - 1][c + j] = ss[j]; }
+      }
     }
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { csum[c + j] = s[j]; csq[c + j] = ss[j]; }
   }
   __syncthreads();
   if (tid < 32) {
     const int cpg = C / 32;
     float s = 0.f, ss = 0.f;
-    for (int j = 0; j < cpg; ++j) { s += csum[tid * cpg + j]; ss += csq[tid * cpg + j]; }
+    for (int j = 0; j < cpg; ++j) {
+      const int c = tid * cpg + j;
+      float a = csum[c], q = csq[c];
+      for (int l = 1; l < PL; ++l) { a += lsum[l - 1][c]; q += lsq[l - 1][c]; }
+      s += a; ss += q;
+    }
     float* dst = p.partial + ((size_t)(b * nchunk + chunk) * 32 + tid) * 2;
     dst[0] = s; dst[1] = ss;
   }
