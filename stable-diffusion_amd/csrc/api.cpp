@@ -118,15 +118,18 @@ int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, in
   if (const char* e = getenv("SDMI_ATTN_NW")) a.nw = atoi(e);     // test / tuning knob
   return launch_attention(a, (hipStream_t)stream);
 }
-int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { return gn_partial_floats(B, HW); }
+int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { return gn_partial_floats(B, HW) + 64; }
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
                      void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream) {
-  SDMI_CHECK(partial_floats >= gn_partial_floats(B, HW), "groupnorm workspace too small");
+  SDMI_CHECK(partial_floats >= gn_partial_floats(B, HW) + 64, "groupnorm workspace too small");
+  // the last 64 words of the workspace are the arrival counters (zeroed here; the kernels leave them zero)
+  unsigned* counter = (unsigned*)(partial_ws + partial_floats - 64);
+  SDMI_HIP_OK(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), (hipStream_t)stream));
   GroupNormParams g;
   g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = HW; g.gamma = gamma; g.beta = beta; g.eps = eps;
   g.silu = silu; g.out_f16 = (f16*)out_f16; g.out_f32 = out_f32; g.raw_f16 = (f16*)raw_f16; g.out_lo = (f16*)out_lo; g.raw_lo = (f16*)raw_lo;
-  g.partial = partial_ws;
+  g.partial = partial_ws; g.counter = counter;
   return launch_groupnorm(g, (hipStream_t)stream);
 }
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,

@@ -100,7 +100,8 @@ struct GroupNormParams {
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
   f16* out_lo = nullptr;       // optional: fp16(y - float(fp16(y)))   -- low half of a split-fp16 operand
   f16* raw_lo = nullptr;       // optional: same for the raw copy
-  float* partial = nullptr;    // workspace, gn_partial_floats(B, HW) floats
+  float* partial = nullptr;    // workspace, gn_partial_floats(B, HW) floats (chunk partials + per-batch {mean, rstd})
+  unsigned* counter = nullptr; // [B] arrival tickets, zero before the launch; the last block of a batch row resets its entry
 };
 int gn_partial_floats(int B, int HW);
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);

@@ -11,7 +11,7 @@
 namespace sdmi {
 namespace {
 
-constexpr int GN_CHUNK = 64;    // pixels per statistics block
+constexpr int GN_CHUNK = 16;    // pixels per statistics block
 constexpr int GN_MAXC = 2560 * 2;
 
 __device__ __forceinline__ f32x4 load_cat4(const float* x0, const float* x1, int c0, int c1, size_t pix, int c) {
@@ -74,40 +74,61 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
     float* dst = p.partial + ((size_t)(b * nchunk + chunk) * 32 + tid) * 2;
     dst[0] = s; dst[1] = ss;
   }
+  // ---- the last block of this batch row to arrive folds all chunk partials into {mean, rstd} ------------------
+  // publish: stores drained by every storing wave -> barrier -> one lane: agent-scope release, then the ticket
+  // (cdna guide, G16 counter form); the last arriver acquires once and reads the partials with plain loads in a
+  // fixed order, so the result does not depend on which block happened to be last.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* s_flag = (int*)&lsq[0][0];                    // reuse LDS (no second __shared__ object needed for a flag)
+  if (tid == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned ticket = __hip_atomic_fetch_add(p.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (ticket == (unsigned)(nchunk - 1));
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    *s_flag = last;
+  }
+  __syncthreads();
+  if (*s_flag) {
+    const int g = tid >> 3, sub = tid & 7;             // 8 lanes per group
+    double s = 0.0, ss = 0.0;
+    for (int ch0 = sub; ch0 < nchunk; ch0 += 64) {
+      float2 v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int ch = ch0 + u * 8;
+        v[u] = (ch < nchunk) ? *(const float2*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2) : float2{0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
+    }
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if (sub == 0) {
+      const double n = (double)(C / 32) * (double)p.HW;
+      const double mean = s / n;
+      double var = ss / n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      float* stats = p.partial + (size_t)p.B * nchunk * 64 + (size_t)(b * 32 + g) * 2;
+      stats[0] = (float)mean;
+      stats[1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+    if (tid == 0) __hip_atomic_store(p.counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next GroupNorm
+  }
 }
 
 constexpr int GN_APPLY_PIX = 8;
 
-// normalise (+SiLU); every block first folds the chunk partials of its batch row into {mean, rstd} per group
-// (8 lanes per group, fp64, fixed order) -- cheaper than a third launch
+// normalise (+SiLU) with the {mean, rstd} the statistics kernel left behind
 __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nchunk) {
   __shared__ float s_mean[32], s_rstd[32];
   const int b = blockIdx.y, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
-  {
-    const int g = tid >> 3, sub = tid & 7;
-    double s = 0.0, ss = 0.0;
-    for (int ch0 = sub; ch0 < nchunk; ch0 += 32) {
-      float2 v[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int ch = ch0 + u * 8;
-        v[u] = (ch < nchunk) ? *(const float2*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2) : float2{0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
-    }
-#pragma unroll
-    for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-    if (sub == 0) {
-      const double n = (double)cpg * (double)p.HW;
-      const double mean = s / n;
-      double var = ss / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      s_mean[g] = (float)mean;
-      s_rstd[g] = (float)(1.0 / sqrt(var + (double)p.eps));
-    }
+  if (tid < 32) {
+    const float* stats = p.partial + (size_t)p.B * nchunk * 64 + (size_t)(b * 32 + tid) * 2;
+    s_mean[tid] = stats[0]; s_rstd[tid] = stats[1];
   }
   __syncthreads();
   const int pix0 = blockIdx.x * GN_APPLY_PIX;
@@ -193,12 +214,12 @@ __global__ void cast_f16_kernel(const float* x, f16* out, f16* out_lo, int64_t n
 
 }  // namespace
 
-int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64; }
+int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64 + B * 64; }
 
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int C = p.c0 + p.c1;
   SDMI_CHECK(C % 32 == 0 && C <= GN_MAXC && p.c0 % 4 == 0 && p.c1 % 4 == 0, "GroupNorm(32) channel constraint");
-  SDMI_CHECK(p.partial != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
+  SDMI_CHECK(p.partial != nullptr && p.counter != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
   SDMI_CHECK(p.c1 == 0 || p.x1 != nullptr, "GroupNorm: second source missing");
   const int nchunk = cdiv(p.HW, GN_CHUNK);
   const double nel = (double)p.B * p.HW * C;

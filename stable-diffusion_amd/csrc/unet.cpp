@@ -323,6 +323,7 @@ struct Fwd {
   UNet* u; hipStream_t s; bool dry; int B, Lctx;
   Arena persist, scratch;
   float* gn_partial = nullptr;
+  unsigned* gn_counter = nullptr;
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   float* emb_all = nullptr;     // [B][emb_total]
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
@@ -366,7 +367,7 @@ struct Fwd {
     g.x0 = x0.p; g.c0 = x0.C;
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
     g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
-    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.partial = gn_partial;
+    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.partial = gn_partial; g.counter = gn_counter;
     if (!dry && !rc) ok(launch_groupnorm(g, s));
   }
 
@@ -583,6 +584,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     }
     const int mc = cfg_.model_channels;
     f.gn_partial = f.P<float>(gn_partial_floats(B, H * W));
+    f.gn_counter = f.P<unsigned>(64);
+    if (!d) SDMI_HIP_OK(hipMemsetAsync(f.gn_counter, 0, 64 * sizeof(unsigned), stream));
     f.splitk_ws_floats = (int64_t)12 << 20;            // 48 MB of fp32 slabs (largest user: 8 x 512 x 1280)
     f.splitk_ws = f.P<float>((size_t)f.splitk_ws_floats);
     f16* ctx16 = f.P<f16>((size_t)B * Lctx * cfg_.context_dim);
