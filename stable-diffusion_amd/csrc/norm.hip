@@ -11,7 +11,9 @@
 namespace sdmi {
 namespace {
 
-constexpr int GN_CHUNK = 16;    // pixels per statistics block
+// pixels per statistics block: small at the low-resolution levels, where the parallelism has to come from
+// many tiny blocks (the kernels are latency-, not bandwidth-bound there)
+static inline int gn_chunk(int HW) { return HW >= 2048 ? 16 : (HW >= 512 ? 8 : 4); }
 constexpr int GN_MAXC = 2560 * 2;
 
 __device__ __forceinline__ f32x4 load_cat4(const float* x0, const float* x1, int c0, int c1, size_t pix, int c) {
@@ -27,14 +29,14 @@ __device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp
 // partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g).
 // Threads are laid out as [pixel lane][channel quad] so that (almost) all 256 threads have loads in flight even
 // at C = 320 (80 quads -> 3 pixel lanes); sums are combined through LDS in a fixed order (deterministic).
-__global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk) {
+__global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk, int chunk_px) {
   __shared__ float csum[GN_MAXC], csq[GN_MAXC];
   __shared__ float lsum[3][1024], lsq[3][1024];       // extra pixel lanes (PL <= 4) for C <= 1024
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int nq = C / 4;
-  const int pix0 = chunk * GN_CHUNK;
-  const int npix = min(GN_CHUNK, p.HW - pix0);
+  const int pix0 = chunk * chunk_px;
+  const int npix = min(chunk_px, p.HW - pix0);
   const int PL = (nq <= 256) ? min(4, 256 / nq) : 1;   // pixel lanes
   const int pl = (nq <= 256) ? tid / nq : 0;
   const int q0 = (nq <= 256) ? tid - pl * nq : tid;
@@ -118,44 +120,38 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
   }
 }
 
-constexpr int GN_APPLY_PIX = 8;
-
-// normalise (+SiLU) with the {mean, rstd} the statistics kernel left behind
+// normalise (+SiLU) with the {mean, rstd} the statistics kernel left behind; one channel quad per thread
 __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nchunk) {
-  __shared__ float s_mean[32], s_rstd[32];
-  const int b = blockIdx.y, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
-  if (tid < 32) {
-    const float* stats = p.partial + (size_t)p.B * nchunk * 64 + (size_t)(b * 32 + tid) * 2;
-    s_mean[tid] = stats[0]; s_rstd[tid] = stats[1];
-  }
-  __syncthreads();
-  const int pix0 = blockIdx.x * GN_APPLY_PIX;
-  const int npix = min(GN_APPLY_PIX, p.HW - pix0);
   const int nq = C / 4;
-  for (int idx = tid; idx < npix * nq; idx += 256) {
-    const int pi = idx / nq;
-    const int c = (idx - pi * nq) * 4;
-    const size_t pix = (size_t)b * p.HW + pix0 + pi;
-    const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, pix, c);
-    const f32x4 ga = *(const f32x4*)(p.gamma + c);
-    const f32x4 be = *(const f32x4*)(p.beta + c);
-    f32x4 y;
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t total = (int64_t)p.B * p.HW * nq;
+  if (idx >= total) return;
+  const size_t pix = (size_t)(idx / nq);               // b * HW + pixel
+  const int c = (int)(idx - (int64_t)pix * nq) * 4;
+  const int b = (int)(pix / p.HW);
+  const float* stats = p.partial + (size_t)p.B * nchunk * 64 + (size_t)b * 64;
+  const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, pix, c);
+  const f32x4 ga = *(const f32x4*)(p.gamma + c);
+  const f32x4 be = *(const f32x4*)(p.beta + c);
+  const int g0 = c / cpg, g1 = (c + 3) / cpg;          // a quad touches at most two groups (cpg >= 2)
+  const float m0 = stats[g0 * 2], r0 = stats[g0 * 2 + 1], m1 = stats[g1 * 2], r1 = stats[g1 * 2 + 1];
+  const int split = (g0 + 1) * cpg - c;                // first channel offset that belongs to g1
+  f32x4 y;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int g = (c + j) / cpg;
-      float t = (v[j] - s_mean[g]) * s_rstd[g] * ga[j] + be[j];
-      if (p.silu) t = t / (1.0f + __expf(-t));
-      y[j] = t;
-    }
-    const size_t o = pix * C + c;
-    if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-    if (p.out_lo) *(f16x4*)(p.out_lo + o) = lo_half(y);
-    if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
-    if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-    if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v);
+  for (int j = 0; j < 4; ++j) {
+    const bool second = j >= split;
+    float t = (v[j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[j] + be[j];
+    if (p.silu) t = t / (1.0f + __expf(-t));
+    y[j] = t;
   }
+  const size_t o = pix * C + c;
+  if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+  if (p.out_lo) *(f16x4*)(p.out_lo + o) = lo_half(y);
+  if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
+  if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v);
 }
 
 // one wave per row
@@ -214,18 +210,21 @@ __global__ void cast_f16_kernel(const float* x, f16* out, f16* out_lo, int64_t n
 
 }  // namespace
 
-int gn_partial_floats(int B, int HW) { return B * cdiv(HW, GN_CHUNK) * 64 + B * 64; }
+int gn_partial_floats(int B, int HW) { return B * cdiv(HW, gn_chunk(HW)) * 64 + B * 64; }
 
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int C = p.c0 + p.c1;
   SDMI_CHECK(C % 32 == 0 && C <= GN_MAXC && p.c0 % 4 == 0 && p.c1 % 4 == 0, "GroupNorm(32) channel constraint");
   SDMI_CHECK(p.partial != nullptr && p.counter != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
   SDMI_CHECK(p.c1 == 0 || p.x1 != nullptr, "GroupNorm: second source missing");
-  const int nchunk = cdiv(p.HW, GN_CHUNK);
+  const int chunk_px = gn_chunk(p.HW);
+  const int nchunk = cdiv(p.HW, chunk_px);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3(cdiv(p.HW, GN_APPLY_PIX), p.B), dim3(256), 0, stream, p, nchunk);
+  SDMI_CHECK(C / 32 >= 2, "GroupNorm: at least 2 channels per group");
+  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
+  const int64_t quads = (int64_t)p.B * p.HW * (C / 4);
+  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, nchunk);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

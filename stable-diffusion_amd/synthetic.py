@@ -29,6 +29,14 @@ def randomize_(unet, seed=0):
     return unet
 
 
+def synthetic_state_dict(unet_kwargs, seed=0):
+    """CPU state_dict (reference key names) of a seeded random SD-v1-architecture UNet."""
+    from .unet import UNetModelHIP
+    m = UNetModelHIP(**unet_kwargs)
+    randomize_(m, seed)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
 SD_V1_UNET_KWARGS = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320,
                          attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
                          use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,

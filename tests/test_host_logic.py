@@ -117,3 +117,30 @@ def test_ldm_shim_schedule_equals_oracle():
     betas, ac = samplers_ref.make_alphas_cumprod()
     assert np.array_equal(ld.alphas_cumprod.numpy(), ac) and np.array_equal(ld.betas.numpy(), betas)
     assert ld.num_timesteps == 1000 and float(ld.alphas_cumprod_prev[0]) == 1.0
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/ldm'), reason='reference checkout only exists in the build container')
+def test_plugin_seam_against_the_real_reference():
+    """The reference's own plugin mechanism (`instantiate_from_config`, ldm/util.py:78-93) resolves the patched
+    `unet_config.target` to UNetModelHIP with the yaml's params, and the resulting state_dict keys / shapes equal the
+    real reference UNetModel's (built on the meta device), so `load_state_dict(sd, strict=False)` fills everything."""
+    import sys
+    import yaml
+    sys.path.insert(0, '/root/reference')
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import run_reference_script as launcher
+    launcher.install_stubs(have_gpu=True)          # stand-ins only; nn.Module.cuda stays untouched
+    from ldm.util import instantiate_from_config
+    cfg = yaml.safe_load(open('/root/reference/configs/stable-diffusion/v1-inference.yaml'))
+    unet_cfg = cfg['model']['params']['unet_config']
+    assert unet_cfg['target'] == 'ldm.modules.diffusionmodules.openaimodel.UNetModel'
+    with torch.device('meta'):
+        ref = instantiate_from_config(unet_cfg)
+    ref_keys = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    unet_cfg = dict(unet_cfg, target='stable_diffusion_amd.unet.UNetModelHIP')
+    with torch.device('meta'):
+        mine = instantiate_from_config(unet_cfg)
+    from stable_diffusion_amd import UNetModelHIP
+    assert isinstance(mine, UNetModelHIP)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == ref_keys
+    assert len(ref_keys) == 686

@@ -1,0 +1,250 @@
+"""Run the reference's UNMODIFIED `scripts/txt2img.py` / `scripts/img2img.py` offline, optionally on the MI355X path.
+
+    python tools/run_reference_script.py [--hip] [--reference /root/reference] txt2img -- --plms --ddim_steps 50 ...
+
+What this launcher does (nothing in the reference tree is edited or copied):
+  * puts minimal stand-ins into `sys.modules` for the third-party imports the scripts need but an offline box lacks
+    (SURVEY.md 8b): omegaconf, pytorch_lightning, torchvision.utils, cv2, imwatermark, diffusers' safety checker,
+    taming, clip, kornia; the HF `from_pretrained` calls (CLIP tokenizer / text model, safety feature extractor) get
+    seeded random-init stand-ins because there is no network;
+  * `--ckpt synthetic[:seed]` makes `torch.load` return a seeded random UNet state_dict under the checkpoint's key names
+    (`model.diffusion_model.*`) -- there is no SD checkpoint in the environment; a real `--ckpt path` is loaded as usual;
+  * `--hip`: writes a patched copy of the reference's `v1-inference.yaml` (only `unet_config.target` changed to
+    `stable_diffusion_amd.unet.UNetModelHIP`) to a temp file, passes it as `--config`, and swaps
+    `ldm.models.diffusion.plms.PLMSSampler` / `ddim.DDIMSampler` for the HIP samplers before the script imports them;
+  * on a GPU-less host (BASELINE.json configs[0], the CPU plumbing check) it neutralises the hard-coded
+    `.cuda()` / `torch.device("cuda")` uses (`txt2img.py:64`, `plms.py:18-22`); use `--precision full` there.
+Then it `runpy`-executes the script with the remaining arguments.
+"""
+import argparse
+import os
+import runpy
+import sys
+import tempfile
+import types
+
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+
+def _module(name, **attrs):
+    import importlib.machinery
+    m = types.ModuleType(name)
+    m.__spec__ = importlib.machinery.ModuleSpec(name, None)
+    m.__dict__.update(attrs)
+    sys.modules[name] = m
+    parent, _, leaf = name.rpartition('.')
+    if parent:
+        if parent not in sys.modules:
+            _module(parent)
+        setattr(sys.modules[parent], leaf, m)
+    return m
+
+
+class AttrDict(dict):
+    """dict with attribute access (what the scripts use of an OmegaConf node)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+    __setattr__ = dict.__setitem__
+
+
+def _wrap(x):
+    if isinstance(x, dict):
+        return AttrDict({k: _wrap(v) for k, v in x.items()})
+    if isinstance(x, list):
+        return ListConfig(_wrap(v) for v in x)
+    return x
+
+
+class ListConfig(list):
+    pass
+
+
+def install_stubs(have_gpu):
+    import yaml
+    import transformers          # before the stand-ins: it probes optional packages (torchvision, ...) via find_spec
+
+    class OmegaConf:
+        @staticmethod
+        def load(path):
+            with open(path) as f:
+                return _wrap(yaml.safe_load(f))
+
+        @staticmethod
+        def to_container(x, resolve=True):
+            return x
+    if 'omegaconf' not in sys.modules:
+        try:
+            import omegaconf  # noqa: F401
+        except ImportError:
+            _module('omegaconf', OmegaConf=OmegaConf)
+            _module('omegaconf.listconfig', ListConfig=ListConfig)
+
+    try:
+        import pytorch_lightning  # noqa: F401
+    except ImportError:
+        class LightningModule(nn.Module):
+            @property
+            def device(self):
+                try:
+                    return next(self.parameters()).device
+                except StopIteration:
+                    return torch.device('cpu')
+
+            def log(self, *a, **k): pass
+            def log_dict(self, *a, **k): pass
+
+        def seed_everything(seed=None):
+            import random
+            import numpy as np
+            random.seed(seed); np.random.seed(seed); torch.manual_seed(seed)
+            return seed
+        _module('pytorch_lightning', LightningModule=LightningModule, seed_everything=seed_everything,
+                Callback=object, Trainer=object)
+        _module('pytorch_lightning.utilities')
+        _module('pytorch_lightning.utilities.distributed', rank_zero_only=lambda f: f)
+
+    try:
+        import torchvision  # noqa: F401
+    except ImportError:
+        def make_grid(t, nrow=8, padding=2, **kw):
+            n, c, h, w = t.shape
+            ncol = min(nrow, n)
+            nr = (n + ncol - 1) // ncol
+            grid = t.new_zeros((c, nr * (h + padding) + padding, ncol * (w + padding) + padding))
+            for i in range(n):
+                r, cc = divmod(i, ncol)
+                y, x = padding + r * (h + padding), padding + cc * (w + padding)
+                grid[:, y:y + h, x:x + w] = t[i]
+            return grid
+        _module('torchvision')
+        _module('torchvision.utils', make_grid=make_grid)
+
+    try:
+        import cv2  # noqa: F401
+    except ImportError:
+        _module('cv2', COLOR_RGB2BGR=4, cvtColor=lambda img, code: img[:, :, ::-1].copy())
+    try:
+        import imwatermark  # noqa: F401
+    except ImportError:
+        class WatermarkEncoder:
+            def set_watermark(self, *a, **k): pass
+            def encode(self, img, method): return img
+        _module('imwatermark', WatermarkEncoder=WatermarkEncoder)
+
+    class _Safety:
+        @classmethod
+        def from_pretrained(cls, *a, **k): return cls()
+        def __call__(self, images, clip_input): return images, [False] * len(images)
+    if 'diffusers' not in sys.modules:
+        _module('diffusers.pipelines.stable_diffusion.safety_checker', StableDiffusionSafetyChecker=_Safety)
+
+    for name in ('clip', 'kornia', 'taming', 'taming.modules', 'taming.modules.vqvae'):
+        if name not in sys.modules:
+            _module(name)
+    _module('taming.modules.vqvae.quantize', VectorQuantizer2=type('VectorQuantizer2', (nn.Module,), {}))
+
+    # ---- HF from_pretrained (network) -> seeded random-init stand-ins ---------------------------------------------
+    import transformers
+
+    class _FeatureExtractor:
+        def __call__(self, images, return_tensors='pt'):
+            return types.SimpleNamespace(pixel_values=torch.zeros(len(images), 3, 224, 224))
+    transformers.AutoFeatureExtractor.from_pretrained = classmethod(lambda cls, *a, **k: _FeatureExtractor())
+
+    class _Tokenizer:
+        """deterministic stand-in: bytes of the prompt -> ids, BOS/EOS/pad like CLIP's (49406 / 49407)."""
+        def __call__(self, text, truncation=True, max_length=77, padding='max_length', return_tensors='pt', **kw):
+            if isinstance(text, str):
+                text = [text]
+            ids = torch.full((len(text), max_length), 49407, dtype=torch.long)
+            for i, s in enumerate(text):
+                toks = [49406] + [1000 + (b * 37) % 40000 for b in s.encode()][:max_length - 2] + [49407]
+                ids[i, :len(toks)] = torch.tensor(toks)
+            return {'input_ids': ids}
+    transformers.CLIPTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: _Tokenizer())
+
+    def _clip_text(cls, *a, **k):
+        cfg = transformers.CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                          num_attention_heads=12, max_position_embeddings=77, hidden_act='quick_gelu')
+        torch.manual_seed(1234)
+        return transformers.CLIPTextModel(cfg)
+    transformers.CLIPTextModel.from_pretrained = classmethod(_clip_text)
+
+    if not have_gpu:   # configs[0]: CPU plumbing run
+        nn.Module.cuda = lambda self, device=None: self
+
+
+def patch_torch_load():
+    real = torch.load
+
+    def load(f, *a, **k):
+        if isinstance(f, str) and f.startswith('synthetic'):
+            seed = int(f.split(':')[1]) if ':' in f else 0
+            from stable_diffusion_amd.synthetic import SD_V1_UNET_KWARGS, synthetic_state_dict
+            sd = synthetic_state_dict(SD_V1_UNET_KWARGS, seed)
+            return {'state_dict': {'model.diffusion_model.' + key: v for key, v in sd.items()}}
+        return real(f, *a, **k)
+    torch.load = load
+
+
+def main():
+    ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument('--reference', default=os.environ.get('SD_REFERENCE', '/root/reference'))
+    ap.add_argument('--hip', action='store_true', help='UNetModelHIP + HIP samplers (needs the MI355X)')
+    ap.add_argument('script', choices=['txt2img', 'img2img'])
+    ap.add_argument('rest', nargs=argparse.REMAINDER)
+    args = ap.parse_args()
+    rest = args.rest[1:] if args.rest[:1] == ['--'] else args.rest
+    ref = os.path.abspath(args.reference)
+    assert os.path.isdir(os.path.join(ref, 'ldm')), f'reference checkout not found at {ref}'
+    sys.path.insert(0, ref)
+    have_gpu = torch.cuda.is_available()
+    if args.hip and not have_gpu:
+        raise SystemExit('--hip needs the MI355X (the HIP path has no CPU fallback)')
+    install_stubs(have_gpu)
+    patch_torch_load()
+
+    import ldm.models.diffusion.ddim as ddim
+    import ldm.models.diffusion.plms as plms
+    if args.hip:
+        from stable_diffusion_amd import DDIMSamplerHIP, PLMSSamplerHIP
+        plms.PLMSSampler, ddim.DDIMSampler = PLMSSamplerHIP, DDIMSamplerHIP
+        src = os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')
+        text = open(src).read()
+        old = 'target: ldm.modules.diffusionmodules.openaimodel.UNetModel'
+        assert old in text
+        tmp = tempfile.NamedTemporaryFile('w', suffix='-mi355x.yaml', delete=False)
+        tmp.write(text.replace(old, 'target: stable_diffusion_amd.unet.UNetModelHIP'))
+        tmp.close()
+        rest = ['--config', tmp.name] + rest
+    elif not have_gpu:
+        for cls in (plms.PLMSSampler, ddim.DDIMSampler):        # plms.py:18-22 hard-codes torch.device("cuda")
+            cls.register_buffer = lambda self, name, attr: setattr(self, name, attr)
+    if not have_gpu:                                            # encoders/modules.py:139 defaults device="cuda"
+        import ldm.modules.encoders.modules as enc
+        _init = enc.FrozenCLIPEmbedder.__init__
+
+        def _cpu_init(self, *a, **k):
+            k.setdefault('device', 'cpu')
+            _init(self, *a, **k)
+        enc.FrozenCLIPEmbedder.__init__ = _cpu_init
+    if '--config' not in rest:
+        rest = ['--config', os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')] + rest
+    script = os.path.join(ref, 'scripts', args.script + '.py')
+    sys.argv = [script] + rest
+    os.chdir(ref if os.access(ref, os.W_OK) else tempfile.mkdtemp())
+    runpy.run_path(script, run_name='__main__')
+
+
+if __name__ == '__main__':
+    main()
