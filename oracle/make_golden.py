@@ -78,6 +78,7 @@ def main():
         ('sdv1_16x16', SD_V1, 0, 2, 16, 16, 77),
         ('sdv1_32x32', SD_V1, 0, 2, 32, 32, 77),
         ('sdv1_64x64', SD_V1, 0, 2, 64, 64, 77),
+        ('sdv1_96x96', SD_V1, 0, 2, 96, 96, 77),     # BASELINE.json configs[3]: 768x768, 9216 tokens
     ]
     ref_models = {}
     for name, cfg, wseed, b, h, w, L in cases:

@@ -35,7 +35,16 @@ namespace {
 
 constexpr int BK = 64;
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (F.gelu default, attention.py:43).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e.
+// 3 orders of magnitude below the fp16 rounding of the GEGLU output) -- the libm erff costs ~3x more VALU.
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752440f;
+  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float erf_abs = 1.0f - poly * __expf(-z * z);
+  const float erf_v = x < 0.f ? -erf_abs : erf_abs;
+  return 0.5f * x * (1.0f + erf_v);
+}
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {   // counted wait: the immediate must be a literal
@@ -401,7 +410,11 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   static const int ablate = env_int("SDMI_IGEMM_ABLATE", 0);
   q.debug = ablate;
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
-  static const std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "s" + std::to_string(NS);
+  static const int by_shape = env_int("SDMI_PROF_SHAPES", 0);
+  std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "s" + std::to_string(NS);
+  if (by_shape && prof_enabled())
+    pname += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + "_k" +
+             std::to_string(p.ksize) + "_m" + std::to_string(p.mode) + "_s" + std::to_string(nsplit);
   const double src_pix = (double)p.B * p.Hin * p.Win;
   const double out_b = (p.out_f32 ? 4.0 : 0.0) + ((p.out_f16 || p.mode != EPI_PLAIN) ? 2.0 : 0.0);
   const double n_out = p.mode == EPI_GEGLU ? p.N / 2.0 : (double)p.N;
@@ -471,7 +484,8 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     splitk = 1;
     if (can_split) {
       const long blocks = (long)cdiv(p.M, BMs[tile]) * cdiv(p.N, BNs[tile]);
-      const long want = (tile == 3) ? 160 : 512;
+      static const int env_want = env_int("SDMI_SPLIT_WANT", 512);
+      const long want = (tile == 3) ? 160 : env_want;
       while (blocks * splitk < want && nkt / (splitk * 2) >= 8 && splitk < 16 &&
              (int64_t)(splitk * 2) * p.M * p.N <= p.splitk_ws_floats)
         splitk *= 2;

@@ -36,7 +36,8 @@ def _model(cfg_name, wseed):
     return _models[key]
 
 
-CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64']
+CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64',
+         'sdv1_96x96']
 
 
 @pytest.mark.parametrize('case', CASES)
