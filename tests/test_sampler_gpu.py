@@ -109,3 +109,33 @@ def test_plms_end_to_end_with_hip_unet():
     print(f'[plms e2e tiny] |x0|max {ref.abs().max():.3f} max-abs {err:.3e}')
     # eps errors (<=1e-3 each) are amplified by CFG 7.5 and accumulated over 11 UNet calls
     assert err < 5e-2
+
+
+def test_img2img_end_to_end_with_hip_unet():
+    """BASELINE.json configs[4] flow (scripts/img2img.py:237-262) on the HIP path: stochastic_encode at t_enc, then
+    DDIM decode through UNetModelHIP, against the oracle loop driving the oracle UNet (DDIM; the reference's img2img
+    rejects --plms, img2img.py:205-207)."""
+    from oracle import samplers_ref, unet_ref
+    from oracle.plan import TINY
+    from oracle.weights import make_inputs, make_state_dict
+    from stable_diffusion_amd import DDIMSamplerHIP, LatentDiffusionHIP, UNetModelHIP
+    sd = make_state_dict(TINY, 0)
+    unet = UNetModelHIP(**TINY.ref_kwargs())
+    unet.load_state_dict(sd, strict=True)
+    ld = LatentDiffusionHIP(unet).cuda()
+    x0, _, ctx = make_inputs(TINY, 1, 16, 16, seed=11)
+    g = torch.Generator().manual_seed(12)
+    noise = torch.randn(x0.shape, generator=g)
+    uc = torch.zeros_like(ctx) - 0.1
+    S, t_enc = 20, 6                                   # strength 0.3 keeps the CPU oracle loop short
+    smp = DDIMSamplerHIP(ld)
+    smp.make_schedule(ddim_num_steps=S, ddim_eta=0.0, verbose=False)
+    z = smp.stochastic_encode(x0.cuda(), torch.tensor([t_enc]).cuda(), noise=noise.cuda())
+    out = smp.decode(z, ctx.cuda(), t_enc, unconditional_guidance_scale=5.0, unconditional_conditioning=uc.cuda())
+    _, ac = samplers_ref.make_alphas_cumprod()
+    z_ref = samplers_ref.ddim_stochastic_encode(ac, S, x0, t_enc, noise)
+    ref = samplers_ref.ddim_decode(lambda x, t, c: unet_ref.unet_forward(sd, TINY, x, t, c), ac, S, z_ref, ctx, t_enc, 5.0, uc)
+    assert (z.cpu() - z_ref).abs().max().item() < 1e-6
+    err = (out.cpu() - ref).abs().max().item()
+    print(f'[img2img e2e tiny] max-abs {err:.3e}')
+    assert err < 3e-2
