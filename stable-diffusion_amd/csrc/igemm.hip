@@ -281,35 +281,89 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   // ---- epilogue ------------------------------------------------------------------------------------
   // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
   const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+  // Full interior tiles take a branch-free path: all residual loads of a 32-row slab are issued back to back
+  // (independent), column terms are hoisted, and no per-element bounds checks split the stores into dependent
+  // load -> wait -> store chains (those chains were ~70 % of the short-K kernels' time, profiles/ablate2_r01.txt).
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
   if (p.mode == EPI_PLAIN) {
     const bool atomic = p.splitk > 1;      // split-K: raw partial sums go to this split's slab
     float* slab = atomic ? (p.splitk_ws + (size_t)split * p.M * p.N) : nullptr;
-    float bias_v[TN];
+    const int b_first = m0 / HWout;
+    const bool one_batch = ((m0 + BM - 1) / HWout == b_first);
+    if (full && one_batch) {
+      if (atomic) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nw + j * 32 + l31;
-      bias_v[j] = (!atomic && p.bias && n < p.N) ? p.bias[n] : 0.f;
-    }
+        for (int i = 0; i < TM; ++i)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+          for (int r = 0; r < 16; ++r) {
+            float* row = slab + (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.N + nw + l31;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-        if (m >= p.M) continue;
-        const float* rv = (!atomic && p.rowvec) ? (p.rowvec + (size_t)(m / HWout) * p.ld_rowvec) : nullptr;
+            for (int j = 0; j < TN; ++j) row[j * 32] = acc[i][j][r];
+          }
+      } else {
+        float colv[TN];
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
           const int n = nw + j * 32 + l31;
-          if (n >= p.N) continue;
-          float v = acc[i][j][r];
-          if (atomic) {
-            slab[(size_t)m * p.N + n] = v;
+          colv[j] = p.bias ? p.bias[n] : 0.f;
+          if (p.rowvec) colv[j] += p.rowvec[(size_t)b_first * p.ld_rowvec + n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float resv[16][TN];
+          if (p.residual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* row = p.residual + (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.ldr + nw + l31;
+#pragma unroll
+              for (int j = 0; j < TN; ++j) resv[r][j] = row[j * 32];
+            }
           } else {
-            v += bias_v[j];
-            if (rv) v += rv[n];
-            if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
-            if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
-            if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) resv[r][j] = 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const size_t ro = (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.ldo + nw + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float v = acc[i][j][r] + colv[j] + resv[r][j];
+              if (p.out_f32) p.out_f32[ro + j * 32] = v;
+              if (p.out_f16) p.out_f16[ro + j * 32] = (f16)v;
+            }
+          }
+        }
+      }
+    } else {
+      float bias_v[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + l31;
+        bias_v[j] = (!atomic && p.bias && n < p.N) ? p.bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (m >= p.M) continue;
+          const float* rv = (!atomic && p.rowvec) ? (p.rowvec + (size_t)(m / HWout) * p.ld_rowvec) : nullptr;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 32 + l31;
+            if (n >= p.N) continue;
+            float v = acc[i][j][r];
+            if (atomic) {
+              slab[(size_t)m * p.N + n] = v;
+            } else {
+              v += bias_v[j];
+              if (rv) v += rv[n];
+              if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+              if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
+              if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
+            }
           }
         }
       }
@@ -322,16 +376,28 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
         if (nv >= p.N) continue;
         const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[nv + 32] : 0.f;
         const int oc = (nw >> 1) + j2 * 32 + l31;
+        if (full) {
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+          for (int i = 0; i < TM; ++i)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-            if (m >= p.M) continue;
-            const float val = acc[i][2 * j2][r] + bv;
-            const float gate = acc[i][2 * j2 + 1][r] + bg;
-            p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
-          }
+            for (int r = 0; r < 16; ++r) {
+              const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              const float val = acc[i][2 * j2][r] + bv;
+              const float gate = acc[i][2 * j2 + 1][r] + bg;
+              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              if (m >= p.M) continue;
+              const float val = acc[i][2 * j2][r] + bv;
+              const float gate = acc[i][2 * j2 + 1][r] + bg;
+              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
+            }
+        }
       }
     }
   } else {  // EPI_HEADS

@@ -19,6 +19,9 @@ SHAPES = {   # B, H, Cin, N, ksize
     'l3conv': (2, 8, 1280, 1280, 3),
     'l0ff2': (2, 64, 1280, 320, 1),
     'big': (2, 64, 1280, 1280, 3),
+    'geglu0': (2, 64, 320, 2560, 1),
+    'geglu1': (2, 32, 640, 5120, 1),
+    'dense0': (2, 64, 320, 320, 1),
 }
 
 
@@ -34,9 +37,16 @@ def main():
     x = torch.randn(B * H * H, Cin, generator=g).half().cuda()
     w = (torch.randn(N, ks * ks * Cin, generator=g) / math.sqrt(ks * ks * Cin)).half().cuda()
     out = torch.empty(B * H * H, N, device='cuda')
+    geglu = a.shape.startswith('geglu')
+    out16 = torch.empty(B * H * H, N // 2, dtype=torch.float16, device='cuda')
+    bias = torch.zeros(N, device='cuda')
+    resid = torch.randn(B * H * H, N, device='cuda') if not geglu else None
     for tile in [int(t) for t in a.tiles.split(',')]:
         for _ in range(a.iters):
-            K.igemm(x, w, N, B, H, H, H, H, ks, 1, 0, out_f32=out, tile=tile, splitk=a.splitk)
+            if geglu:
+                K.igemm(x, w, N, B, H, H, H, H, ks, 1, 0, out_f16=out16, bias=bias, mode=1, tile=tile)
+            else:
+                K.igemm(x, w, N, B, H, H, H, H, ks, 1, 0, out_f32=out, bias=bias, residual=resid, tile=tile, splitk=a.splitk)
         torch.cuda.synchronize()
     print('done')
 
