@@ -115,6 +115,13 @@ int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, in
                      const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
                      void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream);
 int64_t sdmi_k_groupnorm_ws_floats(int B, int HW);
+/* fused GroupNorm(32, eps) + SiLU + conv3x3 (stride 1, pad 1) over cat(x0, x1) fp32 NHWC -> out fp32 [B*H*W][N]
+ * (+bias[n] +rowvec[b][n] +residual); w_packed from sdmi_k_pack_conv_weight; needs H % 8 == 0, W % 16 == 0, N % 64 == 0.
+ * ResBlock in_layers / out_layers, openaimodel.py:201-204,225-231 */
+int sdmi_k_conv3gn(const float* x0, const float* x1, int c0, int c1, int B, int H, int W, const float* gamma,
+                   const float* beta, float eps, const void* w_packed, int N, const float* bias, const float* rowvec,
+                   int ld_rowvec, const float* residual, int ldr, float* out, int ldo, int splitk, float* splitk_ws,
+                   int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, void* stream);
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
                      void* stream);
 int sdmi_k_cast_f16(const float* x, void* out_f16, void* out_lo, int64_t n, void* stream);

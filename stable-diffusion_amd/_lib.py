@@ -53,6 +53,9 @@ _SIGS = {
     'sdmi_k_groupnorm': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, C.c_int,
                                    c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_groupnorm_ws_floats': (C.c_int64, [C.c_int, C.c_int]),
+    'sdmi_k_conv3gn': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, c_ptr,
+                                 C.c_int, c_ptr, c_ptr, C.c_int, c_ptr, C.c_int, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64,
+                                 c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_layernorm': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     'sdmi_k_cast_f16': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_timestep_embedding': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),

@@ -132,6 +132,24 @@ int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, in
   g.partial = partial_ws; g.counter = counter;
   return launch_groupnorm(g, (hipStream_t)stream);
 }
+int sdmi_k_conv3gn(const float* x0, const float* x1, int c0, int c1, int B, int H, int W, const float* gamma,
+                   const float* beta, float eps, const void* w_packed, int N, const float* bias, const float* rowvec,
+                   int ld_rowvec, const float* residual, int ldr, float* out, int ldo, int splitk, float* splitk_ws,
+                   int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, void* stream) {
+  SDMI_CHECK(gn_ws_floats >= gn_partial_floats(B, H * W) + 64, "groupnorm workspace too small");
+  unsigned* counter = (unsigned*)(gn_ws + gn_ws_floats - 64);
+  SDMI_HIP_OK(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), (hipStream_t)stream));
+  GroupNormParams g;
+  g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = H * W; g.gamma = gamma; g.beta = beta; g.eps = eps;
+  g.stats_only = 1; g.partial = gn_ws; g.counter = counter;
+  if (launch_groupnorm(g, (hipStream_t)stream)) return -1;
+  Conv3GnParams c;
+  c.x0 = x0; c.x1 = x1; c.c0 = c0; c.c1 = c1; c.stats = gn_stats_ptr(gn_ws, B, H * W); c.gamma = gamma; c.beta = beta;
+  c.B = B; c.H = H; c.W = W; c.w = (const f16*)w_packed; c.N = N; c.bias = bias; c.rowvec = rowvec; c.ld_rowvec = ld_rowvec;
+  c.residual = residual; c.ldr = ldr; c.out = out; c.ldo = ldo; c.splitk = splitk; c.splitk_ws = splitk_ws;
+  c.splitk_ws_floats = splitk_ws_floats;
+  return launch_conv3gn(c, (hipStream_t)stream);
+}
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
                      void* stream) {
   return launch_layernorm(x, gamma, beta, (f16*)out_f16, M, C, eps, (hipStream_t)stream);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include <string>
 
 typedef _Float16 f16;
@@ -37,7 +38,8 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 // Implicit-GEMM descriptor:  out[M,N] (+epilogue) = gatherA[M,K] * W[N,K]^T
 //   A is fp16 NHWC activations (one or two channel-concatenated sources), gathered as a
 //   1x1 or 3x3 (stride 1/2, optional nearest-x2 upsampled input) convolution; a Linear is ksize=1.
-//   W is fp16 [N][K], K ordered (ky, kx, cin)  -- packed once by pack.hip.
+//   W is fp16 [N][K], K ordered (64-channel chunk, ky, kx, channel within chunk); for 1x1 / Linear simply [N][Cin]
+//   -- packed once by small.hip.
 // ----------------------------------------------------------------------------------------------
 enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 
@@ -76,6 +78,23 @@ struct IGemmTune {        // runtime knobs (tests sweep them; the executor picks
 };
 
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream);
+// out = sum_s slab[s] + bias + rowvec[batch] + residual (fixed order); uses M, N, Hout*Wout, splitk_ws, out_f32/out_f16
+int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
+
+// Fused GroupNorm(32) + SiLU + conv3x3 (stride 1, pad 1) over the fp32 NHWC stream (conv3gn.hip)
+struct Conv3GnParams {
+  const float* x0 = nullptr; const float* x1 = nullptr; int c0 = 0, c1 = 0;   // channel concat [x0 | x1]
+  const float* stats = nullptr;            // [B][32][2] {mean, rstd} from the GroupNorm statistics kernel
+  const float* gamma = nullptr; const float* beta = nullptr;
+  int B = 0, H = 0, W = 0;
+  const f16* w = nullptr; int N = 0;       // [N][9*Cin], chunk-major K order
+  const float* bias = nullptr; const float* rowvec = nullptr; int ld_rowvec = 0;
+  const float* residual = nullptr; int ldr = 0;
+  float* out = nullptr; int ldo = 0;
+  int splitk = 0; float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
+};
+bool conv3gn_supported(int B, int H, int W, int c0, int c1, int N);
+int launch_conv3gn(const Conv3GnParams& p, hipStream_t stream);
 
 // Flash attention over per-head layouts produced by EPI_HEADS
 struct AttnParams {
@@ -95,6 +114,7 @@ struct GroupNormParams {
   int B = 0, HW = 0;
   const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-5f;
   int silu = 0;
+  int stats_only = 0;          // 1: only compute {mean, rstd} (consumed by conv3gn via gn_stats_ptr)
   f16* out_f16 = nullptr;      // [B*HW][C] normalised (+SiLU)
   float* out_f32 = nullptr;    // same in fp32 (used by the output head)
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
@@ -104,6 +124,7 @@ struct GroupNormParams {
   unsigned* counter = nullptr; // [B] arrival tickets, zero before the launch; the last block of a batch row resets its entry
 };
 int gn_partial_floats(int B, int HW);
+const float* gn_stats_ptr(const float* partial, int B, int HW);   // where launch_groupnorm leaves [B][32][2]
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,

@@ -26,6 +26,8 @@
 
 namespace sdmi {
 
+int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
+
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v ? atoi(v) : dflt;
@@ -162,8 +164,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   // load cursor (wave-uniform): next k-tile to issue, its tap and first channel
   int ld_kt = kt_begin;
-  int ld_tap = (kt_begin * BK) / Cin;
-  int ld_cin0 = kt_begin * BK - ld_tap * Cin;
+  // K order is chunk-major: k-tile kt = (64-channel chunk, tap), tap fastest (see pack_conv_kernel)
+  int ld_tap = kt_begin % ntap;
+  int ld_cin0 = (kt_begin / ntap) * BK;
   int ld_ky = pad ? ld_tap / 3 : 0, ld_kx = pad ? ld_tap - 3 * (ld_tap / 3) : 0;
 
   auto issue_loads = [&](int stage) {
@@ -204,11 +207,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     }
     // advance the cursor
     ++ld_kt;
-    ld_cin0 += BK;
-    if (ld_cin0 == Cin) {
-      ld_cin0 = 0; ++ld_tap;
-      if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
-    }
+    ++ld_tap;
+    if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
+    if (ld_tap == ntap) { ld_tap = 0; ld_ky = 0; ld_kx = 0; ld_cin0 += BK; }
   };
   auto commit_regs = [&](int stage) {   // register-staged path: write the prefetched tile into LDS
     if constexpr (!DMA) {
@@ -497,16 +498,20 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   }
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
-  if (nsplit > 1) {
-    const int64_t total = (int64_t)p.M * (p.N / 4);
-    ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, q, nsplit);
-    SDMI_HIP_OK(hipGetLastError());
-  }
+  if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);
   return 0;
 }
 
 }  // namespace
+
+int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
+  SDMI_CHECK(nsplit >= 1 && nsplit <= 16 && p.N % 4 == 0 && p.splitk_ws, "splitk_reduce: bad arguments");
+  const int64_t total = (int64_t)p.M * (p.N / 4);
+  ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, nsplit);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream) {
   SDMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");

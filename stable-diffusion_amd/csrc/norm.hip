@@ -212,6 +212,8 @@ __global__ void cast_f16_kernel(const float* x, f16* out, f16* out_lo, int64_t n
 
 int gn_partial_floats(int B, int HW) { return B * cdiv(HW, gn_chunk(HW)) * 64 + B * 64; }
 
+const float* gn_stats_ptr(const float* partial, int B, int HW) { return partial + (size_t)B * cdiv(HW, gn_chunk(HW)) * 64; }
+
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int C = p.c0 + p.c1;
   SDMI_CHECK(C % 32 == 0 && C <= GN_MAXC && p.c0 % 4 == 0 && p.c1 % 4 == 0, "GroupNorm(32) channel constraint");
@@ -224,7 +226,8 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   SDMI_CHECK(C / 32 >= 2, "GroupNorm: at least 2 channels per group");
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
   const int64_t quads = (int64_t)p.B * p.HW * (C / 4);
-  hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, nchunk);
+  if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo))
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, nchunk);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -146,12 +146,20 @@ __global__ void pack_conv_kernel(const float* w, f16* dst, int O, int I, int KH,
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)O * I * KH * KW;
   if (idx >= total) return;
-  // dst index: ((o*KH + ky)*KW + kx)*I + i
-  const int i = (int)(idx % I);
-  int64_t r = idx / I;
-  const int kx = (int)(r % KW); r /= KW;
-  const int ky = (int)(r % KH);
-  const int o = (int)(r / KH);
+  // K order (chunk-major): k = ((i / 64) * KH*KW + ky*KW + kx) * 64 + i % 64 -- all 9 taps of a 64-channel chunk are
+  // adjacent, so a kernel that stages one input-channel chunk (with its halo) consumes 9 consecutive k-tiles.
+  // For 1x1 convs this is the identity order.  3x3 convs need I % 64 == 0 (checked by the GEMM launcher).
+  const int64_t K = (int64_t)I * KH * KW;
+  const int o = (int)(idx / K);
+  const int64_t k = idx - (int64_t)o * K;
+  int i, ky, kx;
+  if (KH * KW == 1) { i = (int)k; ky = kx = 0; }
+  else {
+    const int chunk = (int)(k / (64 * KH * KW));
+    const int rem = (int)(k - (int64_t)chunk * 64 * KH * KW);
+    const int tap = rem / 64;
+    i = chunk * 64 + rem % 64; ky = tap / KW; kx = tap % KW;
+  }
   dst[idx] = (f16)w[(((int64_t)o * I + i) * KH + ky) * KW + kx];
 }
 __global__ void pack_conv_f32_kernel(const float* w, float* dst, int O, int I, int KH, int KW) {

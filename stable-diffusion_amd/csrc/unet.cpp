@@ -44,6 +44,7 @@ int UNet::build(const sdmi_unet_cfg& c) {
   const int mc = c.model_channels;
   te_ = 4 * mc;
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_FUSE_GN_CONV")) fuse_gn_conv_ = atoi(e) != 0;
   const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
 
   auto add_res = [&](const std::string& p, int cin, int cout) {
@@ -371,36 +372,64 @@ struct Fwd {
     if (!dry && !rc) ok(launch_groupnorm(g, s));
   }
 
+  void gn_stats_only(const Act& x0, const Act* x1, float eps, f16* raw, f16* raw_lo, const float* gamma, const float* beta) {
+    GroupNormParams g;
+    g.x0 = x0.p; g.c0 = x0.C;
+    if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
+    g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = 0;
+    g.raw_f16 = raw; g.raw_lo = raw_lo; g.stats_only = (raw == nullptr && raw_lo == nullptr);
+    g.partial = gn_partial; g.counter = gn_counter;
+    if (!dry && !rc) ok(launch_groupnorm(g, s));
+  }
+
   Act res_block(Layer& L, const Act& x0, const Act* x1) {
     const int H = x0.H, W = x0.W, M = B * H * W;
     const int Cin = x0.C + (x1 ? x1->C : 0), Cout = L.cout;
     if (Cin != L.cin) { ok(fail("res block channel mismatch at " + L.prefix)); }
+    if (Cin == Cout && x1) ok(fail("identity skip with a concatenated input at " + L.prefix));
     const size_t mark = scratch.off;
-    f16* a = S<f16>((size_t)M * Cin);
+    // high-resolution levels: GroupNorm + SiLU fused into the halo-staged 3x3 conv (conv3gn.hip)
+    const bool fused = u->fuse_gn_conv_ && H * W >= 1024 && conv3gn_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout) &&
+                       conv3gn_supported(B, H, W, Cout, 0, Cout);
     f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
     f16* raw_lo = (Cin != Cout && u->precise_1x1_) ? S<f16>((size_t)M * Cin) : nullptr;
-    groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
     float* h = S<float>((size_t)M * Cout);
-    {
+    Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
+    Act hact; hact.p = h; hact.C = Cout; hact.H = H; hact.W = W;
+    const float* stats = dry ? nullptr : gn_stats_ptr(gn_partial, B, H * W);
+    if (fused) {
+      gn_stats_only(x0, x1, 1e-5f, raw, raw_lo, L.f32[0], L.f32[1]);
+      Conv3GnParams c;
+      c.x0 = x0.p; c.c0 = x0.C; if (x1) { c.x1 = x1->p; c.c1 = x1->C; }
+      c.stats = stats; c.gamma = L.f32[0]; c.beta = L.f32[1]; c.B = B; c.H = H; c.W = W;
+      c.w = L.w16[0]; c.N = Cout; c.bias = L.f32[2]; c.rowvec = emb_all + L.emb_off; c.ld_rowvec = u->emb_total_;
+      c.out = h; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
+      if (!dry && !rc) ok(launch_conv3gn(c, s));
+    } else {
+      f16* a = S<f16>((size_t)M * Cin);
+      groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
       IGemmParams p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
       p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = u->emb_total_;
       p.out_f32 = h; p.ldo = Cout;
       gemm(p);
     }
-    f16* a2 = S<f16>((size_t)M * Cout);
-    Act hact; hact.p = h; hact.C = Cout; hact.H = H; hact.W = W;
-    groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
-    Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
     const float* residual = x0.p;
     if (Cin != Cout) {
       IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W);
       p.bias = L.f32[6]; p.out_f32 = out.p; p.ldo = Cout;
       gemm(p);
       residual = out.p;
-    } else if (x1) {
-      ok(fail("identity skip with a concatenated input at " + L.prefix));
     }
-    {
+    if (fused) {
+      gn_stats_only(hact, nullptr, 1e-5f, nullptr, nullptr, L.f32[3], L.f32[4]);
+      Conv3GnParams c;
+      c.x0 = h; c.c0 = Cout; c.stats = stats; c.gamma = L.f32[3]; c.beta = L.f32[4]; c.B = B; c.H = H; c.W = W;
+      c.w = L.w16[1]; c.N = Cout; c.bias = L.f32[5]; c.residual = residual; c.ldr = Cout;
+      c.out = out.p; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
+      if (!dry && !rc) ok(launch_conv3gn(c, s));
+    } else {
+      f16* a2 = S<f16>((size_t)M * Cout);
+      groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
       IGemmParams p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
       p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
       gemm(p);

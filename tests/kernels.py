@@ -166,3 +166,22 @@ def report(name, got, ref, tol):
           f'{d.pow(2).mean().sqrt().item():.3e} at flat {idx}: got {got.flatten()[idx].item():.6f} ref '
           f'{ref.flatten()[idx].item():.6f} nan={bool(torch.isnan(got).any())}', flush=True)
     return mx
+
+
+def conv3gn(x0, x1, gamma, beta, eps, w, bias=None, rowvec=None, residual=None, splitk=0):
+    """x0/x1: fp32 [B, H, W, C]; w: OIHW fp32 -> out fp32 [B*H*W, N]"""
+    B, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    N = w.shape[0]
+    dev = x0.device
+    wp = pack_conv_weight(w)
+    out = torch.full((B * H * W, N), float('nan'), device=dev)
+    n = _lib.load().sdmi_k_groupnorm_ws_floats(B, H * W)
+    gws = torch.empty((n,), dtype=torch.float32, device=dev)
+    ws = torch.empty((16 * B * H * W * N,), dtype=torch.float32, device=dev)
+    _lib.check(_lib.load().sdmi_k_conv3gn(
+        x0.data_ptr(), _lib.ptr(x1), c0, c1, B, H, W, gamma.data_ptr(), beta.data_ptr(), float(eps), wp.data_ptr(), N,
+        _lib.ptr(bias), _lib.ptr(rowvec), 0 if rowvec is None else rowvec.stride(0), _lib.ptr(residual),
+        0 if residual is None else residual.stride(0), out.data_ptr(), N, splitk, ws.data_ptr(), ws.numel(),
+        gws.data_ptr(), n, _s()))
+    return out

@@ -333,3 +333,33 @@ def test_sampler_step_bit_exact(mode, cfg):
     assert torch.equal(e_o.cpu(), e_t), 'post-CFG eps not bit-exact'
     assert torch.equal(p_o.cpu(), pred), 'pred_x0 not bit-exact'
     assert torch.equal(x_o.cpu(), xp), 'x_prev not bit-exact'
+
+
+@pytest.mark.parametrize('B,H,W,c0,c1,N,splitk', [(2, 8, 16, 64, 0, 64, 1), (2, 16, 32, 128, 64, 128, 0), (1, 32, 32, 320, 0, 320, 1),
+                                                  (2, 64, 64, 320, 0, 320, 0), (2, 32, 32, 640, 320, 640, 2), (1, 8, 16, 192, 0, 64, 3)])
+def test_conv3gn_fused(B, H, W, c0, c1, N, splitk):
+    """ResBlock in_layers / out_layers: conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) + bias + emb + residual
+    (openaimodel.py:201-204,225-231,263-275) as one fused kernel with halo-staged input tiles."""
+    g = _g(B * H + c0 + N)
+    C = c0 + c1
+    x0 = torch.randn(B, H, W, c0, generator=g) * 1.3 + 0.2
+    x1 = torch.randn(B, H, W, c1, generator=g) * 0.8 - 0.1 if c1 else None
+    gamma = 1 + 0.1 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    w = torch.randn(N, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    bias = torch.randn(N, generator=g) * 0.1
+    rowvec = torch.randn(B, N, generator=g)
+    resid = torch.randn(B * H * W, N, generator=g)
+    x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
+    xn = F.silu(F.group_norm(x.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5))
+    # the kernel rounds the normalised activation and the weights to fp16 once (MFMA operands), accumulates in fp32
+    ref = F.conv2d(xn.half().float(), w.half().float(), None, padding=1)
+    ref = _nhwc(ref) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
+    out = K.conv3gn(x0.to(DEV), None if x1 is None else x1.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, w.to(DEV),
+                    bias=bias.to(DEV), rowvec=rowvec.to(DEV), residual=resid.to(DEV), splitk=splitk)
+    torch.cuda.synchronize()
+    # vs the fp16-operand reference: the only differences are fp32 GN rounding flips of fp16 operands (<= 1 fp16 ulp on a
+    # handful of A elements) and accumulation order
+    assert K.report(f'conv3gn B{B} {H}x{W} {c0}+{c1}->{N} k{splitk}', out, ref, 3e-3) < 3e-3
+    exact = _nhwc(F.conv2d(xn, w, None, padding=1)) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
+    K.report('   ... vs exact fp32 conv', out, exact, 2e-2)
