@@ -12,7 +12,7 @@
 //
 //   block  = 256 threads = 4 waves (2 x 2), output tile 128 pixels (8 x 16) x 64 channels, wave tile 64 x 32
 //   MFMA   = v_mfma_f32_32x32x16_f16; a 32-row MFMA tile = 2 image rows of 16 pixels
-//   LDS    = A halo 2 x 192 rows x 128 B (180 used) + B 2 x 64 x 128 B = 64 KB  -> 2 blocks / CU
+//   LDS    = A halo 192 rows x 128 B (180 used) + weight ring 6 x 64 x 128 B = 72 KB  -> 2 blocks / CU
 //   A tile is XOR-swizzled per halo pixel hp with ((hp >> 1) & 7) on 16-byte chunks (same scheme as igemm.hip)
 #include "common.h"
 #include "prof.h"
@@ -24,12 +24,13 @@ constexpr int TH = 8, TW = 16, HW2 = TW + 2, HROWS = (TH + 2) * (TW + 2);   // 1
 constexpr int AROWS = 192;                                                    // padded to 6 passes of 32 rows
 constexpr int BN = 64;
 constexpr int A_STAGE = AROWS * 128, B_STAGE = BN * 128;
+constexpr int RB = 6;                                                         // weight-tile ring depth (LDS-DMA)
 
 __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, const int tiles_x, const int tiles_y,
                                                       const int tiles_n, const int chunks_per_split) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * A_STAGE + 2 * B_STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[A_STAGE + RB * B_STAGE];   // 24 + 48 KB -> 2 blocks / CU
   unsigned char* const Asm = smem;
-  unsigned char* const Bsm = smem + 2 * A_STAGE;
+  unsigned char* const Bsm = smem + A_STAGE;
 
   // ---- tile assignment (XCD-aware remap as in igemm.hip; speed only) ---------------------------------------------
   const int nblk = gridDim.x, bid = blockIdx.x;
@@ -98,8 +99,8 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
       shift[j] = p.beta[cc] - stats[g * 2] * rs;
     }
   };
-  auto store_chunk = [&](int stg) {        // normalise + SiLU + fp16 -> LDS halo tile (zeros outside the image)
-    unsigned char* As = Asm + stg * A_STAGE;
+  auto store_chunk = [&]() {               // normalise + SiLU + fp16 -> LDS halo tile (zeros outside the image)
+    unsigned char* As = Asm;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
       const int hp = (tid >> 3) + i * 32;
@@ -145,42 +146,50 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
 
-  // ---- prologue: chunk ch_begin's halo patch + the first weight tile ---------------------------------------------------
+  // ---- main loop over k-tiles it = chunk * 9 + tap -----------------------------------------------------------------------
+  // Weights: ring of RB LDS tiles filled by LDS-DMA, RB-1 tiles in flight, retired by a counted s_waitcnt vmcnt(N)
+  // across a raw s_barrier (the per-tap MFMA work, 8 MFMAs per wave, is far shorter than the L2 latency).
+  // Input: ONE halo stage; the next chunk's patch is loaded into registers at tap 0 (in flight during 9 taps of MFMAs)
+  // and normalised + written to LDS after tap 8, between two barriers.
+  const int it_begin = ch_begin * 9, it_end = ch_end * 9;
   load_chunk(ch_begin);
-  issue_b(ch_begin * 9, 0);
-  store_chunk(0);
-  int bstage = 0;
-  for (int chunk = ch_begin; chunk < ch_end; ++chunk) {
-    const int astage = (chunk - ch_begin) & 1;
+#pragma unroll
+  for (int s0 = 0; s0 < RB - 1; ++s0) issue_b(min(it_begin + s0, it_end - 1), s0);
+  store_chunk();
+  int tap = 0, chunk = ch_begin, slot = 0, nslot = RB - 1;
+  for (int it = it_begin; it < it_end; ++it) {
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // 2 DMA per thread per tile, RB-2 = 4 newer tiles may fly
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    issue_b(min(it + RB - 1, it_end - 1), nslot);              // past the end: harmless reload into a free slot
     const bool more_chunks = (chunk + 1 < ch_end);
-#pragma unroll 1
-    for (int tap = 0; tap < 9; ++tap) {
-      const int it = chunk * 9 + tap;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's share of B(it) (and any staged A loads)
-      __syncthreads();                                        // B(it), A(chunk) visible; previous stages free
-      const bool last_it = (!more_chunks && tap == 8);
-      if (!last_it) issue_b(it + 1, bstage ^ 1);
-      if (tap == 0 && more_chunks) load_chunk(chunk + 1);     // in flight during this tap's MFMAs
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const unsigned char* As = Asm + astage * A_STAGE;
-      const unsigned char* Bs = Bsm + bstage * B_STAGE + brow * 128;
-      int hp[2], asw[2];
+    if (tap == 0 && more_chunks) load_chunk(chunk + 1);
+    const int ky = tap / 3, kx = tap - ky * 3;
+    const unsigned char* As = Asm;
+    const unsigned char* Bs = Bsm + slot * B_STAGE + brow * 128;
+    int hp[2], asw[2];
 #pragma unroll
-      for (int i = 0; i < 2; ++i) { hp[i] = hp0[i] + ky * HW2 + kx; asw[i] = (hp[i] >> 1) & 7; }
+    for (int i = 0; i < 2; ++i) { hp[i] = hp0[i] + ky * HW2 + kx; asw[i] = (hp[i] >> 1) & 7; }
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const int c = ks * 2 + lg;
-        const f16x8 bf = *(const f16x8*)(Bs + ((c ^ bsw) << 4));
+    for (int ks = 0; ks < 4; ++ks) {
+      const int c = ks * 2 + lg;
+      const f16x8 bf = *(const f16x8*)(Bs + ((c ^ bsw) << 4));
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const f16x8 af = *(const f16x8*)(As + hp[i] * 128 + ((c ^ asw[i]) << 4));
-          acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[i], 0, 0, 0);
-        }
+      for (int i = 0; i < 2; ++i) {
+        const f16x8 af = *(const f16x8*)(As + hp[i] * 128 + ((c ^ asw[i]) << 4));
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc[i], 0, 0, 0);
       }
-      if (tap == 1 && more_chunks) store_chunk(astage ^ 1);   // other A stage: last read during the previous chunk
-      bstage ^= 1;
+    }
+    slot = (slot + 1 == RB) ? 0 : slot + 1;
+    nslot = (nslot + 1 == RB) ? 0 : nslot + 1;
+    if (++tap == 9) {
+      tap = 0; ++chunk;
+      if (more_chunks) {
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the halo tile
+        store_chunk();                                                      // published by the next iteration's barrier
+      }
     }
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
   // ---- epilogue (tiles are always full: H % 8 == 0, W % 16 == 0, N % 64 == 0) -----------------------------------------
   const int n = n0 + wn * 32 + l31;
