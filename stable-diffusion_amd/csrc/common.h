@@ -92,6 +92,7 @@ struct Conv3GnParams {
   const float* residual = nullptr; int ldr = 0;
   float* out = nullptr; int ldo = 0;
   int splitk = 0; float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
+  int debug = 0;     // perf ablation only (SDMI_CONV3GN_ABLATE): 1 no weight loads, 2 no MFMA work, 4 no input staging
 };
 bool conv3gn_supported(int B, int H, int W, int c0, int c1, int N);
 int launch_conv3gn(const Conv3GnParams& p, hipStream_t stream);

@@ -109,7 +109,7 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
       for (int j = 0; j < 8; ++j) {
         const float x = stage[i][j >> 2][j & 3];
         float t = x * scale[j] + shift[j];
-        t = t / (1.0f + __expf(-t));
+        t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));     // SiLU; 1-ulp reciprocal, the result is rounded to fp16 anyway
         o[j] = (a_src[i] >= 0) ? (f16)t : (f16)0.f;
       }
       *(f16x8*)(As + hp * 128 + ((oct ^ ((hp >> 1) & 7)) << 4)) = o;
@@ -160,15 +160,16 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
   for (int it = it_begin; it < it_end; ++it) {
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");            // 2 DMA per thread per tile, RB-2 = 4 newer tiles may fly
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    issue_b(min(it + RB - 1, it_end - 1), nslot);              // past the end: harmless reload into a free slot
+    if (!(p.debug & 1)) issue_b(min(it + RB - 1, it_end - 1), nslot);   // past the end: harmless reload into a free slot
     const bool more_chunks = (chunk + 1 < ch_end);
-    if (tap == 0 && more_chunks) load_chunk(chunk + 1);
+    if (tap == 0 && more_chunks && !(p.debug & 4)) load_chunk(chunk + 1);
     const int ky = tap / 3, kx = tap - ky * 3;
     const unsigned char* As = Asm;
     const unsigned char* Bs = Bsm + slot * B_STAGE + brow * 128;
     int hp[2], asw[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) { hp[i] = hp0[i] + ky * HW2 + kx; asw[i] = (hp[i] >> 1) & 7; }
+    if (!(p.debug & 2))
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int c = ks * 2 + lg;
@@ -185,7 +186,7 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
       tap = 0; ++chunk;
       if (more_chunks) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // every wave is done reading the halo tile
-        store_chunk();                                                      // published by the next iteration's barrier
+        if (!(p.debug & 4)) store_chunk();                                  // published by the next iteration's barrier
       }
     }
   }
@@ -254,6 +255,8 @@ int launch_conv3gn(const Conv3GnParams& p, hipStream_t stream) {
   const int nsplit = cdiv(nchunks, cps);
   Conv3GnParams q = p;
   q.splitk = nsplit;
+  static const char* abl = getenv("SDMI_CONV3GN_ABLATE");
+  q.debug = abl ? atoi(abl) : 0;
   {
     const double M = (double)p.B * p.H * p.W, Cin = p.c0 + p.c1;
     ProfScope ps("conv3gn_8x16x64", 2.0 * M * p.N * 9.0 * Cin, M * Cin * 4.0 + (double)p.N * 9.0 * Cin * 2.0 + M * p.N * 4.0 +

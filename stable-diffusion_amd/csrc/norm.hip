@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nc
   for (int j = 0; j < 4; ++j) {
     const bool second = j >= split;
     float t = (v[j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[j] + be[j];
-    if (p.silu) t = t / (1.0f + __expf(-t));
+    if (p.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
     y[j] = t;
   }
   const size_t o = pix * C + c;
