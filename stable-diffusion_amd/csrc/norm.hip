@@ -73,19 +73,20 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
       for (int l = 1; l < PL; ++l) { a += lsum[l - 1][c]; q += lsq[l - 1][c]; }
       s += a; ss += q;
     }
-    float* dst = p.partial + ((size_t)(b * nchunk + chunk) * 32 + tid) * 2;
-    dst[0] = s; dst[1] = ss;
+    // write-through (sc1) 8-byte store: visible at agent scope without a release fence (a release would write back
+    // the whole L2 -- buffer_wbl2 -- in every one of the ~1000 blocks; cdna guide G16, recipe R1)
+    union { float2 f; unsigned long long u; } pk; pk.f = float2{s, ss};
+    __hip_atomic_store((unsigned long long*)(p.partial + ((size_t)(b * nchunk + chunk) * 32 + tid) * 2), pk.u,
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // ---- the last block of this batch row to arrive folds all chunk partials into {mean, rstd} ------------------
-  // publish: stores drained by every storing wave -> barrier -> one lane: agent-scope release, then the ticket
-  // (cdna guide, G16 counter form); the last arriver acquires once and reads the partials with plain loads in a
-  // fixed order, so the result does not depend on which block happened to be last.
+  // publish: write-through stores drained by the storing wave -> barrier -> one lane takes a relaxed agent-scope
+  // ticket; the last arriver acquires once (L1 invalidate) and reads the partials in a fixed order, so the result does
+  // not depend on which block happened to be last.
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   int* s_flag = (int*)&lsq[0][0];                    // reuse LDS (no second __shared__ object needed for a flag)
   if (tid == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const unsigned ticket = __hip_atomic_fetch_add(p.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (ticket == (unsigned)(nchunk - 1));
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -100,7 +101,12 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         const int ch = ch0 + u * 8;
-        v[u] = (ch < nchunk) ? *(const float2*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2) : float2{0.f, 0.f};
+        if (ch < nchunk) {
+          union { float2 f; unsigned long long u; } pk;
+          pk.u = __hip_atomic_load((const unsigned long long*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          v[u] = pk.f;
+        } else v[u] = float2{0.f, 0.f};
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
