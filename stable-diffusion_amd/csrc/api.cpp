@@ -118,33 +118,31 @@ int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, in
   if (const char* e = getenv("SDMI_ATTN_NW")) a.nw = atoi(e);     // test / tuning knob
   return launch_attention(a, (hipStream_t)stream);
 }
-int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { return gn_partial_floats(B, HW) + 64; }
+int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { (void)HW; return gn_acc_words(B) * 2; }
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
                      void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream) {
-  SDMI_CHECK(partial_floats >= gn_partial_floats(B, HW) + 64, "groupnorm workspace too small");
-  // the last 64 words of the workspace are the arrival counters (zeroed here; the kernels leave them zero)
-  unsigned* counter = (unsigned*)(partial_ws + partial_floats - 64);
-  SDMI_HIP_OK(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), (hipStream_t)stream));
+  SDMI_CHECK(partial_floats >= gn_acc_words(B) * 2, "groupnorm workspace too small");
+  // the workspace holds the fixed-point statistics accumulators; they must start at zero
+  SDMI_HIP_OK(hipMemsetAsync(partial_ws, 0, gn_acc_words(B) * sizeof(long long), (hipStream_t)stream));
   GroupNormParams g;
   g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = HW; g.gamma = gamma; g.beta = beta; g.eps = eps;
   g.silu = silu; g.out_f16 = (f16*)out_f16; g.out_f32 = out_f32; g.raw_f16 = (f16*)raw_f16; g.out_lo = (f16*)out_lo; g.raw_lo = (f16*)raw_lo;
-  g.partial = partial_ws; g.counter = counter;
+  g.acc = (long long*)partial_ws;
   return launch_groupnorm(g, (hipStream_t)stream);
 }
 int sdmi_k_conv3gn(const float* x0, const float* x1, int c0, int c1, int B, int H, int W, const float* gamma,
                    const float* beta, float eps, const void* w_packed, int N, const float* bias, const float* rowvec,
                    int ld_rowvec, const float* residual, int ldr, float* out, int ldo, int splitk, float* splitk_ws,
                    int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, void* stream) {
-  SDMI_CHECK(gn_ws_floats >= gn_partial_floats(B, H * W) + 64, "groupnorm workspace too small");
-  unsigned* counter = (unsigned*)(gn_ws + gn_ws_floats - 64);
-  SDMI_HIP_OK(hipMemsetAsync(counter, 0, 64 * sizeof(unsigned), (hipStream_t)stream));
+  SDMI_CHECK(gn_ws_floats >= gn_acc_words(B) * 2, "groupnorm workspace too small");
+  SDMI_HIP_OK(hipMemsetAsync(gn_ws, 0, gn_acc_words(B) * sizeof(long long), (hipStream_t)stream));
   GroupNormParams g;
   g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = H * W; g.gamma = gamma; g.beta = beta; g.eps = eps;
-  g.stats_only = 1; g.partial = gn_ws; g.counter = counter;
+  g.stats_only = 1; g.acc = (long long*)gn_ws;
   if (launch_groupnorm(g, (hipStream_t)stream)) return -1;
   Conv3GnParams c;
-  c.x0 = x0; c.x1 = x1; c.c0 = c0; c.c1 = c1; c.stats = gn_stats_ptr(gn_ws, B, H * W); c.gamma = gamma; c.beta = beta;
+  c.x0 = x0; c.x1 = x1; c.c0 = c0; c.c1 = c1; c.acc = (const long long*)gn_ws; c.eps = eps; c.gamma = gamma; c.beta = beta;
   c.B = B; c.H = H; c.W = W; c.w = (const f16*)w_packed; c.N = N; c.bias = bias; c.rowvec = rowvec; c.ld_rowvec = ld_rowvec;
   c.residual = residual; c.ldr = ldr; c.out = out; c.ldo = ldo; c.splitk = splitk; c.splitk_ws = splitk_ws;
   c.splitk_ws_floats = splitk_ws_floats;

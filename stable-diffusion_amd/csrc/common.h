@@ -84,7 +84,8 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
 // Fused GroupNorm(32) + SiLU + conv3x3 (stride 1, pad 1) over the fp32 NHWC stream (conv3gn.hip)
 struct Conv3GnParams {
   const float* x0 = nullptr; const float* x1 = nullptr; int c0 = 0, c1 = 0;   // channel concat [x0 | x1]
-  const float* stats = nullptr;            // [B][32][2] {mean, rstd} from the GroupNorm statistics kernel
+  const long long* acc = nullptr;          // statistics accumulators of the preceding GroupNorm stats launch
+  float eps = 1e-5f;
   const float* gamma = nullptr; const float* beta = nullptr;
   int B = 0, H = 0, W = 0;
   const f16* w = nullptr; int N = 0;       // [N][9*Cin], chunk-major K order
@@ -121,11 +122,14 @@ struct GroupNormParams {
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
   f16* out_lo = nullptr;       // optional: fp16(y - float(fp16(y)))   -- low half of a split-fp16 operand
   f16* raw_lo = nullptr;       // optional: same for the raw copy
-  float* partial = nullptr;    // workspace, gn_partial_floats(B, HW) floats (chunk partials + per-batch {mean, rstd})
-  unsigned* counter = nullptr; // [B] arrival tickets, zero before the launch; the last block of a batch row resets its entry
+  // fixed-point statistics accumulators of THIS GroupNorm call: [B][32 groups][8 slots][{sum * 2^32, sumsq * 2^28}] int64,
+  // zero before the launch.  Integer atomics are associative, so the statistics are bit-reproducible without a
+  // finalize pass or inter-block ordering; consumers fold the 8 slots with gn_mean_rstd().
+  long long* acc = nullptr;
 };
-int gn_partial_floats(int B, int HW);
-const float* gn_stats_ptr(const float* partial, int B, int HW);   // where launch_groupnorm leaves [B][32][2]
+constexpr int GN_SLOTS = 8;
+constexpr int GN_MAX_CALLS = 96;   // accumulator regions per UNet forward (SD v1 has 61 GroupNorms)
+static inline int64_t gn_acc_words(int B) { return (int64_t)B * 32 * GN_SLOTS * 2; }   // int64 words per GroupNorm call
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,

@@ -72,7 +72,24 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
     a_src[i] = v;
   }
   const int cpg = Cin / 32;
-  const float* stats = p.stats + (size_t)b * 64;
+  // fold this batch row's GroupNorm accumulators (8 lanes per group) into an LDS {mean, rstd} table
+  __shared__ float s_tab[64];
+  float* const s_stats = s_tab;
+  {
+    const long long* src = p.acc + ((size_t)(b * 32 + (tid >> 3)) * GN_SLOTS + (tid & 7)) * 2;
+    long long s = src[0], ss = src[1];
+#pragma unroll
+    for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    if ((tid & 7) == 0) {
+      const double n = (double)cpg * (double)p.H * (double)p.W;
+      const double m = (double)s * (1.0 / 4294967296.0) / n;
+      double var = (double)ss * (1.0 / 268435456.0) / n - m * m;
+      if (var < 0.0) var = 0.0;
+      s_stats[(tid >> 3) * 2] = (float)m;
+      s_stats[(tid >> 3) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));
+    }
+  }
+  __syncthreads();
   f32x4 stage[6][2];                       // raw fp32 input of the next chunk (12 x 16 B in flight per thread)
   float scale[8], shift[8];                // y = x * scale + shift  (GroupNorm affine folded)
 
@@ -94,9 +111,9 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
     for (int j = 0; j < 8; ++j) {
       const int cc = c + j;
       const int g = cc / cpg;
-      const float rs = stats[g * 2 + 1] * p.gamma[cc];
+      const float rs = s_tab[g * 2 + 1] * p.gamma[cc];
       scale[j] = rs;
-      shift[j] = p.beta[cc] - stats[g * 2] * rs;
+      shift[j] = p.beta[cc] - s_tab[g * 2] * rs;
     }
   };
   auto store_chunk = [&]() {               // normalise + SiLU + fp16 -> LDS halo tile (zeros outside the image)
@@ -237,7 +254,7 @@ bool conv3gn_supported(int B, int H, int W, int c0, int c1, int N) {
 
 int launch_conv3gn(const Conv3GnParams& p, hipStream_t stream) {
   SDMI_CHECK(conv3gn_supported(p.B, p.H, p.W, p.c0, p.c1, p.N), "conv3gn: unsupported shape");
-  SDMI_CHECK(p.x0 && p.stats && p.gamma && p.beta && p.w && p.out, "conv3gn: missing pointer");
+  SDMI_CHECK(p.x0 && p.acc && p.gamma && p.beta && p.w && p.out, "conv3gn: missing pointer");
   SDMI_CHECK(p.c1 == 0 || p.x1 != nullptr, "conv3gn: second source missing");
   const int tiles_x = p.W / TW, tiles_y = p.H / TH, tiles_n = p.N / BN;
   const int nchunks = (p.c0 + p.c1) / 64;

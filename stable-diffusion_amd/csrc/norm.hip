@@ -26,9 +26,10 @@ __device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp
   return r;
 }
 
-// partial[(b * nchunk + chunk) * 32 + g] = {sum, sumsq} over (chunk pixels) x (channels of group g).
-// Threads are laid out as [pixel lane][channel quad] so that (almost) all 256 threads have loads in flight even
-// at C = 320 (80 quads -> 3 pixel lanes); sums are combined through LDS in a fixed order (deterministic).
+// Statistics: every block reduces its pixel chunk to one {sum, sumsq} per group and adds them, as fixed-point
+// int64 (sum * 2^32, sumsq * 2^28), into one of GN_SLOTS accumulator slots of (b, g).  Integer addition is associative:
+// the totals are bit-identical whatever the block order, with no finalize kernel and no inter-block ordering.
+// Threads are laid out as [pixel lane][channel quad] so (almost) all 256 threads have loads in flight even at C = 320.
 __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk, int chunk_px) {
   __shared__ float csum[GN_MAXC], csq[GN_MAXC];
   __shared__ float lsum[3][1024], lsq[3][1024];       // extra pixel lanes (PL <= 4) for C <= 1024
@@ -73,76 +74,48 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
       for (int l = 1; l < PL; ++l) { a += lsum[l - 1][c]; q += lsq[l - 1][c]; }
       s += a; ss += q;
     }
-    // write-through (sc1) 8-byte store: visible at agent scope without a release fence (a release would write back
-    // the whole L2 -- buffer_wbl2 -- in every one of the ~1000 blocks; cdna guide G16, recipe R1)
-    union { float2 f; unsigned long long u; } pk; pk.f = float2{s, ss};
-    __hip_atomic_store((unsigned long long*)(p.partial + ((size_t)(b * nchunk + chunk) * 32 + tid) * 2), pk.u,
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
-  // ---- the last block of this batch row to arrive folds all chunk partials into {mean, rstd} ------------------
-  // publish: write-through stores drained by the storing wave -> barrier -> one lane takes a relaxed agent-scope
-  // ticket; the last arriver acquires once (L1 invalidate) and reads the partials in a fixed order, so the result does
-  // not depend on which block happened to be last.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int* s_flag = (int*)&lsq[0][0];                    // reuse LDS (no second __shared__ object needed for a flag)
-  if (tid == 0) {
-    const unsigned ticket = __hip_atomic_fetch_add(p.counter + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (ticket == (unsigned)(nchunk - 1));
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    *s_flag = last;
-  }
-  __syncthreads();
-  if (*s_flag) {
-    const int g = tid >> 3, sub = tid & 7;             // 8 lanes per group
-    double s = 0.0, ss = 0.0;
-    for (int ch0 = sub; ch0 < nchunk; ch0 += 64) {
-      float2 v[8];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        const int ch = ch0 + u * 8;
-        if (ch < nchunk) {
-          union { float2 f; unsigned long long u; } pk;
-          pk.u = __hip_atomic_load((const unsigned long long*)(p.partial + ((size_t)(b * nchunk + ch) * 32 + g) * 2),
-                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          v[u] = pk.f;
-        } else v[u] = float2{0.f, 0.f};
-      }
-#pragma unroll
-      for (int u = 0; u < 8; ++u) { s += (double)v[u].x; ss += (double)v[u].y; }
-    }
-#pragma unroll
-    for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-    if (sub == 0) {
-      const double n = (double)(C / 32) * (double)p.HW;
-      const double mean = s / n;
-      double var = ss / n - mean * mean;
-      if (var < 0.0) var = 0.0;
-      float* stats = p.partial + (size_t)p.B * nchunk * 64 + (size_t)(b * 32 + g) * 2;
-      stats[0] = (float)mean;
-      stats[1] = (float)(1.0 / sqrt(var + (double)p.eps));
-    }
-    if (tid == 0) __hip_atomic_store(p.counter + b, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next GroupNorm
+    unsigned long long* dst = (unsigned long long*)p.acc + ((size_t)(b * 32 + tid) * GN_SLOTS + (chunk & (GN_SLOTS - 1))) * 2;
+    atomicAdd(dst, (unsigned long long)__double2ll_rn((double)s * 4294967296.0));
+    atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)ss * 268435456.0));
   }
 }
 
-// normalise (+SiLU) with the {mean, rstd} the statistics kernel left behind; one channel quad per thread
-__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, int nchunk) {
+// fold the GN_SLOTS accumulators of (b, g): called by 8 consecutive lanes (sub = lane & 7), result valid on sub == 0
+__device__ __forceinline__ void gn_fold(const long long* acc, int b, int g, int sub, double n, float eps, float* mean,
+                                        float* rstd) {
+  const long long* src = acc + ((size_t)(b * 32 + g) * GN_SLOTS + sub) * 2;
+  long long s = src[0], ss = src[1];
+#pragma unroll
+  for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+  const double m = (double)s * (1.0 / 4294967296.0) / n;
+  double var = (double)ss * (1.0 / 268435456.0) / n - m * m;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)m;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// normalise (+SiLU); one channel quad per thread; grid (blocks per batch row, B)
+__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p) {
+  __shared__ float s_mean[32], s_rstd[32];
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
   const int nq = C / 4;
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t total = (int64_t)p.B * p.HW * nq;
-  if (idx >= total) return;
-  const size_t pix = (size_t)(idx / nq);               // b * HW + pixel
-  const int c = (int)(idx - (int64_t)pix * nq) * 4;
-  const int b = (int)(pix / p.HW);
-  const float* stats = p.partial + (size_t)p.B * nchunk * 64 + (size_t)b * 64;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  {
+    float m, r;
+    gn_fold(p.acc, b, tid >> 3, tid & 7, (double)cpg * (double)p.HW, p.eps, &m, &r);
+    if ((tid & 7) == 0) { s_mean[tid >> 3] = m; s_rstd[tid >> 3] = r; }
+  }
+  __syncthreads();
+  const int64_t idx = (int64_t)blockIdx.x * 256 + tid;          // quad index inside this batch row
+  if (idx >= (int64_t)p.HW * nq) return;
+  const size_t pix = (size_t)b * p.HW + (size_t)(idx / nq);
+  const int c = (int)(idx % nq) * 4;
   const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, pix, c);
   const f32x4 ga = *(const f32x4*)(p.gamma + c);
   const f32x4 be = *(const f32x4*)(p.beta + c);
   const int g0 = c / cpg, g1 = (c + 3) / cpg;          // a quad touches at most two groups (cpg >= 2)
-  const float m0 = stats[g0 * 2], r0 = stats[g0 * 2 + 1], m1 = stats[g1 * 2], r1 = stats[g1 * 2 + 1];
+  const float m0 = s_mean[g0], r0 = s_rstd[g0], m1 = s_mean[g1], r1 = s_rstd[g1];
   const int split = (g0 + 1) * cpg - c;                // first channel offset that belongs to g1
   f32x4 y;
 #pragma unroll
@@ -216,24 +189,21 @@ __global__ void cast_f16_kernel(const float* x, f16* out, f16* out_lo, int64_t n
 
 }  // namespace
 
-int gn_partial_floats(int B, int HW) { return B * cdiv(HW, gn_chunk(HW)) * 64 + B * 64; }
-
-const float* gn_stats_ptr(const float* partial, int B, int HW) { return partial + (size_t)B * cdiv(HW, gn_chunk(HW)) * 64; }
-
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int C = p.c0 + p.c1;
   SDMI_CHECK(C % 32 == 0 && C <= GN_MAXC && p.c0 % 4 == 0 && p.c1 % 4 == 0, "GroupNorm(32) channel constraint");
-  SDMI_CHECK(p.partial != nullptr && p.counter != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
+  SDMI_CHECK(p.acc != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
   SDMI_CHECK(p.c1 == 0 || p.x1 != nullptr, "GroupNorm: second source missing");
+  SDMI_CHECK(C / 32 >= 2, "GroupNorm: at least 2 channels per group");
   const int chunk_px = gn_chunk(p.HW);
   const int nchunk = cdiv(p.HW, chunk_px);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
-  SDMI_CHECK(C / 32 >= 2, "GroupNorm: at least 2 channels per group");
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
-  const int64_t quads = (int64_t)p.B * p.HW * (C / 4);
-  if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo))
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, stream, p, nchunk);
+  if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
+    const int64_t quads = (int64_t)p.HW * (C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p);
+  }
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

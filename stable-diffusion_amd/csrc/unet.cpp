@@ -323,8 +323,13 @@ struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
 struct Fwd {
   UNet* u; hipStream_t s; bool dry; int B, Lctx;
   Arena persist, scratch;
-  float* gn_partial = nullptr;
-  unsigned* gn_counter = nullptr;
+  long long* gn_acc = nullptr;   // GN_MAX_CALLS regions of gn_acc_words(B) int64, zeroed once per forward
+  int gn_calls = 0;
+  long long* next_gn_acc() {
+    if (gn_calls >= GN_MAX_CALLS) { ok(fail("more GroupNorm calls than accumulator regions")); return gn_acc; }
+    return gn_acc + (size_t)(gn_calls++) * gn_acc_words(B);
+  }
+  long long* last_gn_acc() const { return gn_acc + (size_t)(gn_calls - 1) * gn_acc_words(B); }
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   float* emb_all = nullptr;     // [B][emb_total]
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
@@ -368,7 +373,7 @@ struct Fwd {
     g.x0 = x0.p; g.c0 = x0.C;
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
     g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
-    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.partial = gn_partial; g.counter = gn_counter;
+    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.acc = next_gn_acc();
     if (!dry && !rc) ok(launch_groupnorm(g, s));
   }
 
@@ -378,7 +383,7 @@ struct Fwd {
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
     g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = 0;
     g.raw_f16 = raw; g.raw_lo = raw_lo; g.stats_only = (raw == nullptr && raw_lo == nullptr);
-    g.partial = gn_partial; g.counter = gn_counter;
+    g.acc = next_gn_acc();
     if (!dry && !rc) ok(launch_groupnorm(g, s));
   }
 
@@ -396,12 +401,11 @@ struct Fwd {
     float* h = S<float>((size_t)M * Cout);
     Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
     Act hact; hact.p = h; hact.C = Cout; hact.H = H; hact.W = W;
-    const float* stats = dry ? nullptr : gn_stats_ptr(gn_partial, B, H * W);
     if (fused) {
       gn_stats_only(x0, x1, 1e-5f, raw, raw_lo, L.f32[0], L.f32[1]);
       Conv3GnParams c;
       c.x0 = x0.p; c.c0 = x0.C; if (x1) { c.x1 = x1->p; c.c1 = x1->C; }
-      c.stats = stats; c.gamma = L.f32[0]; c.beta = L.f32[1]; c.B = B; c.H = H; c.W = W;
+      c.acc = last_gn_acc(); c.eps = 1e-5f; c.gamma = L.f32[0]; c.beta = L.f32[1]; c.B = B; c.H = H; c.W = W;
       c.w = L.w16[0]; c.N = Cout; c.bias = L.f32[2]; c.rowvec = emb_all + L.emb_off; c.ld_rowvec = u->emb_total_;
       c.out = h; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
       if (!dry && !rc) ok(launch_conv3gn(c, s));
@@ -423,7 +427,7 @@ struct Fwd {
     if (fused) {
       gn_stats_only(hact, nullptr, 1e-5f, nullptr, nullptr, L.f32[3], L.f32[4]);
       Conv3GnParams c;
-      c.x0 = h; c.c0 = Cout; c.stats = stats; c.gamma = L.f32[3]; c.beta = L.f32[4]; c.B = B; c.H = H; c.W = W;
+      c.x0 = h; c.c0 = Cout; c.acc = last_gn_acc(); c.eps = 1e-5f; c.gamma = L.f32[3]; c.beta = L.f32[4]; c.B = B; c.H = H; c.W = W;
       c.w = L.w16[1]; c.N = Cout; c.bias = L.f32[5]; c.residual = residual; c.ldr = Cout;
       c.out = out.p; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
       if (!dry && !rc) ok(launch_conv3gn(c, s));
@@ -600,7 +604,7 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
   for (int pass = (dry ? 0 : 0); pass < 2; ++pass) {
     const bool d = (pass == 0) ? true : false;
     if (pass == 1 && dry) break;
-    f.dry = d; f.rc = 0;
+    f.dry = d; f.rc = 0; f.gn_calls = 0;
     f.persist = Arena(); f.scratch = Arena();
     f.persist.dry = f.scratch.dry = d;
     if (!d) {
@@ -612,9 +616,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       if (ensure_ctx_cache(B, Lctx)) return -1;
     }
     const int mc = cfg_.model_channels;
-    f.gn_partial = f.P<float>(gn_partial_floats(B, H * W));
-    f.gn_counter = f.P<unsigned>(64);
-    if (!d) SDMI_HIP_OK(hipMemsetAsync(f.gn_counter, 0, 64 * sizeof(unsigned), stream));
+    f.gn_acc = f.P<long long>((size_t)GN_MAX_CALLS * gn_acc_words(B));
+    if (!d) SDMI_HIP_OK(hipMemsetAsync(f.gn_acc, 0, (size_t)GN_MAX_CALLS * gn_acc_words(B) * sizeof(long long), stream));
     f.splitk_ws_floats = (int64_t)12 << 20;            // 48 MB of fp32 slabs (largest user: 8 x 512 x 1280)
     f.splitk_ws = f.P<float>((size_t)f.splitk_ws_floats);
     f16* ctx16 = f.P<f16>((size_t)B * Lctx * cfg_.context_dim);
