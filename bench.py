@@ -5,7 +5,8 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is one image per GPU: `PLMSSamplerHIP.sample` (51 UNet calls through libsdmi's gfx950 kernels, fused
-CFG + PLMS update) followed by the VAE decode on stock PyTorch-ROCm (north_star keeps the VAE there).  Weights are
+CFG + PLMS update) followed by the first-stage decode, also through libsdmi (`AutoencoderKLHIP`, SURVEY.md 8 f-1;
+`--vae torch` runs the decoder on stock PyTorch-ROCm instead, for A/B).  Weights are
 seeded random tensors in the exact SD-v1 architecture and the conditioning is synthetic (there is no checkpoint /
 CLIP vocabulary in the environment); throughput is value independent.  N > 1: one process per GPU, one prompt per
 GPU (weak scaling), no data-path collective; the finished latents are all-gathered once per step (RCCL).
@@ -32,25 +33,48 @@ HBM_PEAK_GBS = 8000.0
 UNET_GFLOP_64 = 1606.5        # one UNet call, CFG batch 2, latent 64x64
 
 
-def build_gpu_model(device, seed=0):
-    from stable_diffusion_amd import LatentDiffusionHIP, UNetModelHIP
-    from stable_diffusion_amd.synthetic import SD_V1_UNET_KWARGS, randomize_
-    from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
+def build_gpu_model(device, seed=0, vae_kind='hip'):
+    from stable_diffusion_amd import AutoencoderKLHIP, LatentDiffusionHIP, UNetModelHIP
+    from stable_diffusion_amd.synthetic import SD_V1_UNET_KWARGS, SD_V1_VAE_DDCONFIG, randomize_, randomize_vae_
     unet = UNetModelHIP(**SD_V1_UNET_KWARGS)
     ld = LatentDiffusionHIP(unet).to(device).eval()
     randomize_(unet, seed)
-    torch.manual_seed(seed)
-    vae = AutoencoderKLDecoder().to(device).eval()
+    if vae_kind == 'hip':       # the first stage on the same gfx950 kernels (decoder part only)
+        vae = AutoencoderKLHIP(SD_V1_VAE_DDCONFIG, None, 4, parts=1).to(device).eval()
+        randomize_vae_(vae, seed)
+    else:                       # A/B: the decoder on stock PyTorch-ROCm (fp16 autocast), what north_star started from
+        from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
+        torch.manual_seed(seed)
+        vae = AutoencoderKLDecoder().to(device).eval()
     return ld, unet, vae
+
+
+def decode(vae, lat):
+    """decode_first_stage + the script's clamp to [0, 1] (ddpm.py:705-763, scripts/txt2img.py:313-314)"""
+    if hasattr(vae, '_handle'):
+        img = vae.decode_first_stage(lat)
+    else:
+        with torch.autocast('cuda', dtype=torch.float16):
+            img = vae.decode_first_stage(lat)
+    return torch.clamp((img.float() + 1.0) / 2.0, min=0.0, max=1.0)
 
 
 def one_image(sampler, vae, c, uc, x_T, steps_plms=50, scale=7.5):
     lat, _ = sampler.sample(S=steps_plms, batch_size=1, shape=list(x_T.shape[1:]), conditioning=c, verbose=False,
                             x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=uc, eta=0.0)
-    with torch.autocast('cuda', dtype=torch.float16):
-        img = vae.decode_first_stage(lat)
-    img = torch.clamp((img.float() + 1.0) / 2.0, min=0.0, max=1.0)     # scripts/txt2img.py:314
-    return lat, img
+    return lat, decode(vae, lat)
+
+
+def vae_latency_ms(vae, device, iters=5):
+    g = torch.Generator(device='cpu').manual_seed(4)
+    lat = (torch.randn(1, 4, 64, 64, generator=g) * 0.9).to(device)
+    decode(vae, lat)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        decode(vae, lat)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / iters * 1e3
 
 
 def profile_unet(unet, device, H=64, W=64):
@@ -123,13 +147,13 @@ def usable_cores():
 
 
 def cpu_baseline(n_unet_calls=2):
-    """The oracle (fp32 CPU restatement of the reference UNet) + the VAE decoder on the host cores; bounded sample:
+    """The oracle (fp32 CPU restatements of the reference UNet and first-stage decoder) on the host cores; bounded sample:
     `n_unet_calls` UNet calls at the full workload shape (CFG batch 2, latent 64x64) and one VAE decode, extrapolated
     to 51 calls + 1 decode per image."""
     from oracle import unet_ref
     from oracle.plan import SD_V1
     from oracle.weights import make_inputs, make_state_dict
-    from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
+    from oracle import vae_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
     sd = make_state_dict(SD_V1, 0)
@@ -142,11 +166,10 @@ def cpu_baseline(n_unet_calls=2):
         if times[-1] > 20.0:          # keep the sample bounded on slow hosts
             break
     t_unet = min(times)
-    torch.manual_seed(0)
-    vae = AutoencoderKLDecoder().eval()
-    z = torch.randn(1, 4, 64, 64)
+    vsd = vae_ref.make_vae_state_dict(vae_ref.SD_VAE, 0, encoder=False)
+    z = vae_ref.make_vae_inputs(vae_ref.SD_VAE, 1, 64, 64, seed=1) * 0.18215
     t0 = time.perf_counter()
-    vae.decode_first_stage(z)
+    vae_ref.decode_first_stage(vsd, vae_ref.SD_VAE, z)
     t_vae = time.perf_counter() - t0
     s_per_image = 51 * t_unet + t_vae
     return {'value': 1.0 / s_per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
@@ -161,6 +184,7 @@ def main():
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
+    ap.add_argument('--vae', choices=['hip', 'torch'], default='hip', help='first-stage decode: libsdmi (default) or PyTorch-ROCm')
     args = ap.parse_args()
 
     from stable_diffusion_amd import PLMSSamplerHIP
@@ -173,7 +197,7 @@ def main():
     device = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
-    ld, unet, vae = build_gpu_model(device)
+    ld, unet, vae = build_gpu_model(device, vae_kind=args.vae)
     sampler = PLMSSamplerHIP(ld)
     # synthetic conditioning / start codes; the seed depends on the GLOBAL prompt index only
     def inputs(step):
@@ -218,14 +242,15 @@ def main():
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': 'SD-v1-4 UNet (859.5M params, random init), latent 4x64x64 (512x512), 50 PLMS steps = '
-                                   '51 UNet calls at CFG batch 2, scale 7.5, 1 prompt per GPU per step, + VAE decode '
-                                   '(PyTorch-ROCm fp16 autocast)',
+                                   '51 UNet calls at CFG batch 2, scale 7.5, 1 prompt per GPU per step, + VAE decode ' +
+                                   ('(libsdmi AutoencoderKLHIP)' if args.vae == 'hip' else '(PyTorch-ROCm fp16 autocast)'),
                        'global_batch': world, 'parallelism': f'dp{world} (one prompt per GPU, latents all_gather)'},
         }
         if world == 1:
             ms = unet_latency_ms(unet, device)
             out['unet_ms_per_call'] = ms
             out['unet_tflops'] = UNET_GFLOP_64 / ms
+            out['vae_decode_ms'] = vae_latency_ms(vae, device)
             if not args.no_roofline:
                 table = profile_unet(unet, device)
                 table.sort(key=lambda r: -r['ms'])

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 1
+#define SDMI_ABI_VERSION 2
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -53,7 +53,7 @@ int sdmi_unet_destroy(sdmi_unet* h);
 int sdmi_unet_num_weights(const sdmi_unet* h);
 int sdmi_unet_weight_info(const sdmi_unet* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim);
 /* model.load_state_dict (scripts/txt2img.py:56): fp32 tensor in the reference layout (conv OIHW, linear [out,in]);
- * `ptr` may be a device or a host pointer.  The library repacks (fp16 [N][K], K=(ky,kx,cin)) and keeps its own copy. */
+ * `ptr` may be a device or a host pointer.  The library repacks (fp16 [N][K], K ordered (64-channel chunk, ky, kx, channel)) and keeps its own copy. */
 int sdmi_unet_set_weight(sdmi_unet* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream);
 /* fails (listing the first missing key) unless every expected tensor was set */
 int sdmi_unet_finalize(sdmi_unet* h);
@@ -86,12 +86,49 @@ int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float*
                       const float* old1, const float* old2, float a_t, float a_prev, float sigma, float sqrt_1m_at,
                       const float* noise, float* e_t_out, float* x_prev, float* pred_x0, int64_t n, void* stream);
 
+
+/* ---- first stage (AutoencoderKL): SURVEY.md 8 f-1 ---------------------------------------------------------------
+ * Replaces instantiate_from_config(first_stage_config) (ddpm.py:462-467) for inference:
+ * `decode_first_stage` (ddpm.py:705-763) -> AutoencoderKL.decode (autoencoder.py:330-333) -> Decoder.forward
+ * (ldm/modules/diffusionmodules/model.py:528-568), and `encode_first_stage` (ddpm.py:825-863) ->
+ * AutoencoderKL.encode (autoencoder.py:324-328) -> Encoder.forward (model.py:427-460). */
+typedef struct sdmi_vae sdmi_vae;
+/* ddconfig of configs/stable-diffusion/v1-inference.yaml:51-65 (attn_resolutions = [], dropout 0, double_z) + embed_dim */
+typedef struct sdmi_vae_cfg {
+  int32_t ch;
+  int32_t out_ch;
+  int32_t n_levels;
+  int32_t ch_mult[8];
+  int32_t num_res_blocks;
+  int32_t in_channels;
+  int32_t z_channels;
+  int32_t embed_dim;
+} sdmi_vae_cfg;
+/* parts: 1 = decoder (+post_quant_conv), 2 = encoder (+quant_conv), 3 = both */
+int sdmi_vae_create(const sdmi_vae_cfg* cfg, int parts, sdmi_vae** out);
+int sdmi_vae_destroy(sdmi_vae* h);
+/* the state_dict keys the handle expects (= AutoencoderKL.state_dict() of the chosen parts, without `loss.*`) */
+int sdmi_vae_num_weights(const sdmi_vae* h);
+int sdmi_vae_weight_info(const sdmi_vae* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim);
+int sdmi_vae_set_weight(sdmi_vae* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream);
+int sdmi_vae_finalize(sdmi_vae* h);
+/* z fp32 [B, embed_dim, H, W] -> img fp32 [B, out_ch, H*f, W*f], f = 2^(n_levels-1); z is multiplied by z_scale first
+ * (decode_first_stage passes 1/scale_factor, ddpm.py:713; AutoencoderKL.decode passes 1) */
+int64_t sdmi_vae_decode_workspace_bytes(sdmi_vae* h, int B, int H, int W);
+int sdmi_vae_decode(sdmi_vae* h, const float* z, float z_scale, float* img, int B, int H, int W, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+/* img fp32 [B, in_channels, H, W] (H, W multiples of f) -> moments fp32 [B, 2*embed_dim, H/f, W/f]: the parameters of
+ * DiagonalGaussianDistribution (mean | logvar), ldm/modules/distributions/distributions.py:24-33 */
+int64_t sdmi_vae_encode_workspace_bytes(sdmi_vae* h, int B, int H, int W);
+int sdmi_vae_encode(sdmi_vae* h, const float* img, float* moments, int B, int H, int W, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 /* ---- kernel-level entry points (parity tests and micro-benchmarks; same kernels the UNet uses) ---------- */
 typedef struct sdmi_igemm_desc {
   const void* a0; const void* a1; const void* a2;   /* fp16 NHWC sources, channel concat [a0|a1|a2] (a1, a2 optional) */
   int32_t c0, c1, c2, lda0, lda1, lda2;
   int32_t B, Hin, Win, Hout, Wout, ksize, stride, up;
-  const void* w;                        /* fp16 [N][K], K = ksize*ksize*(c0+c1+c2) ordered (ky,kx,cin) */
+  const void* w;                        /* fp16 [N][K] from sdmi_k_pack_conv_weight: K = ksize*ksize*(c0+c1+c2), ordered (64-ch chunk, ky, kx, ch) */
   int32_t N;
   int32_t mode;                         /* 0 plain, 1 GEGLU (w/bias packed by sdmi_k_pack_geglu), 2 per-head scatter */
   const float* bias; const float* rowvec; int32_t ld_rowvec;
@@ -104,6 +141,8 @@ typedef struct sdmi_igemm_desc {
   int32_t tile;                         /* -1 auto; 0 128x128, 1 128x64, 2 64x64, 3 256x128 (8 waves) -- double buffered;
                                            4 128x64, 5 64x64 with a 3-stage LDS-DMA pipeline */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
+  int32_t asym_pad;                     /* 3x3 only: 0 = zero pad 1 on every side; 1 = pad right/bottom only, i.e.
+                                           F.pad(x,(0,1,0,1)) + conv(padding=0) of the VAE Downsample (model.py:72-76) */
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
@@ -136,6 +175,10 @@ int sdmi_k_pack_conv_weight(const float* w_oihw, void* dst_f16, int O, int I, in
 int sdmi_k_pack_conv_out(const float* w_oihw, float* dst_ohwi, int O, int I, void* stream);
 /* [N][K] fp32 -> fp16 [N][3K] = [hi | hi | lo] for the 3-pass split-fp16 1x1 convs */
 int sdmi_k_pack_split3(const float* w, void* dst_f16, int N, int K, void* stream);
+/* first-stage helpers: 1x1 conv NCHW->NCHW on <= 16 channels (input pre-scaled); row softmax fp32 -> fp16 */
+int sdmi_k_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int HW,
+                          float in_scale, void* stream);
+int sdmi_k_softmax_rows(const float* S, void* P_f16, int rows, int cols, float scale, void* stream);
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst_f16, float* bdst, int N, int K, void* stream);
 /* per-launch timing of the library's kernels (HIP events on the launch stream): begin, run forwards, then end
  * writes a JSON array [{"name","launches","ms","flops","bytes"}] (algorithmic flops / bytes per kernel class) */

@@ -16,6 +16,12 @@ class UNetCfg(C.Structure):
                 ('num_heads', C.c_int32), ('transformer_depth', C.c_int32), ('context_dim', C.c_int32)]
 
 
+class VaeCfg(C.Structure):
+    _fields_ = [('ch', C.c_int32), ('out_ch', C.c_int32), ('n_levels', C.c_int32), ('ch_mult', C.c_int32 * 8),
+                ('num_res_blocks', C.c_int32), ('in_channels', C.c_int32), ('z_channels', C.c_int32),
+                ('embed_dim', C.c_int32)]
+
+
 class IGemmDesc(C.Structure):
     _fields_ = [('a0', c_ptr), ('a1', c_ptr), ('a2', c_ptr),
                 ('c0', C.c_int32), ('c1', C.c_int32), ('c2', C.c_int32),
@@ -29,7 +35,7 @@ class IGemmDesc(C.Structure):
                 ('seg_dst', c_ptr * 3), ('seg_kind', C.c_int32 * 3),
                 ('heads', C.c_int32), ('dh', C.c_int32), ('ntok', C.c_int32), ('ntok_pad', C.c_int32),
                 ('segC', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', c_ptr), ('splitk_ws_floats', C.c_int64),
-                ('tile', C.c_int32), ('dma', C.c_int32)]
+                ('tile', C.c_int32), ('dma', C.c_int32), ('asym_pad', C.c_int32)]
 
 
 _SIGS = {
@@ -47,7 +53,19 @@ _SIGS = {
                                     c_ptr, C.c_int64, c_ptr]),
     'sdmi_sampler_step': (C.c_int, [c_ptr, C.c_int, C.c_float, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr, C.c_float,
                                     C.c_float, C.c_float, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_vae_create': (C.c_int, [C.POINTER(VaeCfg), C.c_int, C.POINTER(c_ptr)]),
+    'sdmi_vae_destroy': (C.c_int, [c_ptr]),
+    'sdmi_vae_num_weights': (C.c_int, [c_ptr]),
+    'sdmi_vae_weight_info': (C.c_int, [c_ptr, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    'sdmi_vae_set_weight': (C.c_int, [c_ptr, C.c_char_p, c_ptr, C.POINTER(C.c_int64), C.c_int, c_ptr]),
+    'sdmi_vae_finalize': (C.c_int, [c_ptr]),
+    'sdmi_vae_decode_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int, C.c_int]),
+    'sdmi_vae_decode': (C.c_int, [c_ptr, c_ptr, C.c_float, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_vae_encode_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int, C.c_int]),
+    'sdmi_vae_encode': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_igemm': (C.c_int, [C.POINTER(IGemmDesc), c_ptr]),
+    'sdmi_k_pointwise_nchw': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_ptr]),
+    'sdmi_k_softmax_rows': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     'sdmi_k_attention': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                    C.c_float, c_ptr]),
     'sdmi_k_groupnorm': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, C.c_int,
@@ -91,7 +109,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 1:
+        if lib.sdmi_abi_version() != 2:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -5,6 +5,7 @@
 
 #include "prof.h"
 #include "unet.h"
+#include "vae.h"
 
 namespace sdmi {
 static thread_local std::string g_err;
@@ -13,6 +14,7 @@ int fail(const std::string& msg) { g_err = msg; return -1; }
 }  // namespace sdmi
 
 struct sdmi_unet { sdmi::UNet impl; };
+struct sdmi_vae { sdmi::Vae impl; };
 
 using namespace sdmi;
 
@@ -92,6 +94,63 @@ int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float*
   return launch_sampler_step(p, (hipStream_t)stream);
 }
 
+
+// ---- first stage --------------------------------------------------------------------------------------
+int sdmi_vae_create(const sdmi_vae_cfg* cfg, int parts, sdmi_vae** out) {
+  SDMI_CHECK(cfg && out, "null argument");
+  sdmi_vae* h = new (std::nothrow) sdmi_vae();
+  SDMI_CHECK(h != nullptr, "out of host memory");
+  if (h->impl.build(*cfg, parts)) { delete h; return -1; }
+  *out = h;
+  return 0;
+}
+int sdmi_vae_destroy(sdmi_vae* h) { delete h; return 0; }
+int sdmi_vae_num_weights(const sdmi_vae* h) { return h ? (int)h->impl.slots().size() : fail("null handle"); }
+int sdmi_vae_weight_info(const sdmi_vae* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim) {
+  SDMI_CHECK(h && key_buf && shape4 && ndim, "null argument");
+  SDMI_CHECK(idx >= 0 && idx < (int)h->impl.slots().size(), "weight index out of range");
+  const VWeightSlot& s = h->impl.slots()[idx];
+  SDMI_CHECK((int)s.key.size() + 1 <= key_buf_len, "key buffer too small");
+  memcpy(key_buf, s.key.c_str(), s.key.size() + 1);
+  *ndim = (int)s.shape.size();
+  for (int i = 0; i < 4; ++i) shape4[i] = i < *ndim ? s.shape[i] : 1;
+  return 0;
+}
+int sdmi_vae_set_weight(sdmi_vae* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream) {
+  SDMI_CHECK(h && key && ptr && shape, "null argument");
+  return h->impl.set_weight(key, ptr, shape, ndim, (hipStream_t)stream);
+}
+int sdmi_vae_finalize(sdmi_vae* h) { SDMI_CHECK(h, "null handle"); return h->impl.finalize(); }
+int64_t sdmi_vae_decode_workspace_bytes(sdmi_vae* h, int B, int H, int W) {
+  if (!h) { fail("null handle"); return 0; }
+  int64_t need = 0;
+  if (h->impl.decode(nullptr, 1.f, nullptr, B, H, W, nullptr, 0, nullptr, true, &need)) return 0;
+  return need;
+}
+int sdmi_vae_decode(sdmi_vae* h, const float* z, float z_scale, float* img, int B, int H, int W, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  SDMI_CHECK(h && z && img, "null argument");
+  return h->impl.decode(z, z_scale, img, B, H, W, workspace, workspace_bytes, (hipStream_t)stream, false, nullptr);
+}
+int64_t sdmi_vae_encode_workspace_bytes(sdmi_vae* h, int B, int H, int W) {
+  if (!h) { fail("null handle"); return 0; }
+  int64_t need = 0;
+  if (h->impl.encode(nullptr, nullptr, B, H, W, nullptr, 0, nullptr, true, &need)) return 0;
+  return need;
+}
+int sdmi_vae_encode(sdmi_vae* h, const float* img, float* moments, int B, int H, int W, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  SDMI_CHECK(h && img && moments, "null argument");
+  return h->impl.encode(img, moments, B, H, W, workspace, workspace_bytes, (hipStream_t)stream, false, nullptr);
+}
+int sdmi_k_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int HW,
+                          float in_scale, void* stream) {
+  return launch_pointwise_nchw(x, w, bias, out, B, Cin, Cout, HW, in_scale, (hipStream_t)stream);
+}
+int sdmi_k_softmax_rows(const float* S, void* P_f16, int rows, int cols, float scale, void* stream) {
+  return launch_softmax_rows(S, (f16*)P_f16, rows, cols, cols, cols, scale, (hipStream_t)stream);
+}
+
 // ---- kernel-level entry points ------------------------------------------------------------------------
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   SDMI_CHECK(d, "null descriptor");
@@ -99,7 +158,7 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   p.a0 = (const f16*)d->a0; p.a1 = (const f16*)d->a1; p.a2 = (const f16*)d->a2;
   p.c0 = d->c0; p.c1 = d->c1; p.c2 = d->c2; p.lda0 = d->lda0; p.lda1 = d->lda1; p.lda2 = d->lda2;
   p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
-  p.ksize = d->ksize; p.stride = d->stride; p.up = d->up;
+  p.ksize = d->ksize; p.stride = d->stride; p.up = d->up; p.pad = d->asym_pad ? 0 : 1;
   p.w = (const f16*)d->w; p.M = d->B * d->Hout * d->Wout; p.N = d->N; p.K = d->ksize * d->ksize * (d->c0 + d->c1 + d->c2);
   p.mode = d->mode; p.bias = d->bias; p.rowvec = d->rowvec; p.ld_rowvec = d->ld_rowvec;
   p.residual = d->residual; p.ldr = d->ldr; p.out_f32 = d->out_f32; p.out_f16 = (f16*)d->out_f16; p.ldo = d->ldo;
@@ -118,7 +177,7 @@ int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, in
   if (const char* e = getenv("SDMI_ATTN_NW")) a.nw = atoi(e);     // test / tuning knob
   return launch_attention(a, (hipStream_t)stream);
 }
-int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { (void)HW; return gn_acc_words(B) * 2; }
+int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { (void)HW; return gn_acc_words(B) * 2; }   // int64 words, counted in floats
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
                      void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream) {

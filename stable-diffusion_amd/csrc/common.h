@@ -13,6 +13,19 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
+#ifdef __HIPCC__
+// GroupNorm statistics words (see GroupNormParams::acc): add one fp32 partial / read a folded total
+__device__ __forceinline__ void gn_acc_add(unsigned long long* dst, float v) {
+  const double d = (double)v;
+  const double hi = rint(d);
+  atomicAdd(dst, (unsigned long long)(long long)hi);
+  atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((d - hi) * 1099511627776.0));
+}
+__device__ __forceinline__ double gn_acc_value(long long hi, long long lo) {
+  return (double)hi + (double)lo * (1.0 / 1099511627776.0);
+}
+#endif
+
 namespace sdmi {
 
 // thread-local error text surfaced through sdmi_last_error()
@@ -50,6 +63,7 @@ struct IGemmParams {
   int B = 1, Hin = 1, Win = 1;                         // source spatial dims (M = B*Hout*Wout)
   int Hout = 1, Wout = 1;
   int ksize = 1, stride = 1, up = 0;
+  int pad = 1;                                         // 3x3 only: 1 = symmetric zero pad; 0 = pad right/bottom only (taps at +0..+2)
   const f16* w = nullptr;                              // [N][K]
   int M = 0, N = 0, K = 0;
   // epilogue
@@ -122,14 +136,16 @@ struct GroupNormParams {
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
   f16* out_lo = nullptr;       // optional: fp16(y - float(fp16(y)))   -- low half of a split-fp16 operand
   f16* raw_lo = nullptr;       // optional: same for the raw copy
-  // fixed-point statistics accumulators of THIS GroupNorm call: [B][32 groups][8 slots][{sum * 2^32, sumsq * 2^28}] int64,
-  // zero before the launch.  Integer atomics are associative, so the statistics are bit-reproducible without a
-  // finalize pass or inter-block ordering; consumers fold the 8 slots with gn_mean_rstd().
+  // fixed-point statistics accumulators of THIS GroupNorm call: [B][32 groups][GN_SLOTS][GN_WORDS] int64, zero before
+  // the launch.  Each of {sum, sumsq} is kept as an integer part and a 2^-40 fraction (two words), so the range is that
+  // of an int64 and nothing can wrap.  Integer atomics are associative: the statistics are bit-reproducible without a
+  // finalize pass or inter-block ordering; consumers fold the slots themselves (gn_fold in norm.hip).
   long long* acc = nullptr;
 };
 constexpr int GN_SLOTS = 8;
 constexpr int GN_MAX_CALLS = 96;   // accumulator regions per UNet forward (SD v1 has 61 GroupNorms)
-static inline int64_t gn_acc_words(int B) { return (int64_t)B * 32 * GN_SLOTS * 2; }   // int64 words per GroupNorm call
+constexpr int GN_WORDS = 4;         // {sum int, sum frac * 2^40, sumsq int, sumsq frac * 2^40}
+static inline int64_t gn_acc_words(int B) { return (int64_t)B * 32 * GN_SLOTS * GN_WORDS; }   // int64 words per GroupNorm call
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,
@@ -144,6 +160,11 @@ int launch_conv_in(const float* x_nchw, const float* w, const float* bias, float
                    int W, int Cout, hipStream_t s);
 int launch_conv_out(const float* h_nhwc, const float* w_khwc, const float* bias, float* out_nchw, int B, int H, int W,
                     int Cin, int Cout, hipStream_t s);
+
+// first-stage (VAE) helpers
+int launch_pointwise_nchw(const float* x_nchw, const float* w, const float* bias, float* out_nchw, int B, int Cin, int Cout,
+                          int HW, float in_scale, hipStream_t s);
+int launch_softmax_rows(const float* S, f16* P, int rows, int cols, int lds, int ldp, float scale, hipStream_t s);
 
 // weight packing (device pointers, fp32 reference layouts -> packed)
 int launch_pack_conv_weight(const float* w_oihw, f16* dst, int O, int I, int KH, int KW, hipStream_t s);  // -> [O][KH][KW][I]

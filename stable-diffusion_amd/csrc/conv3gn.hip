@@ -76,14 +76,16 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
   __shared__ float s_tab[64];
   float* const s_stats = s_tab;
   {
-    const long long* src = p.acc + ((size_t)(b * 32 + (tid >> 3)) * GN_SLOTS + (tid & 7)) * 2;
-    long long s = src[0], ss = src[1];
+    const long long* src = p.acc + ((size_t)(b * 32 + (tid >> 3)) * GN_SLOTS + (tid & 7)) * GN_WORDS;
+    long long s = src[0], sl = src[1], ss = src[2], ssl = src[3];
 #pragma unroll
-    for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
+    for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {
+      s += __shfl_xor(s, o); sl += __shfl_xor(sl, o); ss += __shfl_xor(ss, o); ssl += __shfl_xor(ssl, o);
+    }
     if ((tid & 7) == 0) {
       const double n = (double)cpg * (double)p.H * (double)p.W;
-      const double m = (double)s * (1.0 / 4294967296.0) / n;
-      double var = (double)ss * (1.0 / 268435456.0) / n - m * m;
+      const double m = gn_acc_value(s, sl) / n;
+      double var = gn_acc_value(ss, ssl) / n - m * m;
       if (var < 0.0) var = 0.0;
       s_stats[(tid >> 3) * 2] = (float)m;
       s_stats[(tid >> 3) * 2 + 1] = (float)(1.0 / sqrt(var + (double)p.eps));

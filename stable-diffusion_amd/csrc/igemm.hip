@@ -111,7 +111,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   // are tabulated per row instead.)
   const int HWout = p.Hout * p.Wout;
   const int Cin = p.c0 + p.c1 + p.c2;
-  const int pad = (p.ksize == 3) ? 1 : 0;
+  const bool k3 = p.ksize == 3;
+  const int pad = k3 ? p.pad : 0;                   // 1, or 0 for the VAE encoder's (0,1,0,1)-padded stride-2 conv
   const int ntap = p.ksize * p.ksize;
   const int ld = p.lda0;                            // all sources share the row pitch (checked by the launcher)
   int a_off[A_PASSES]; unsigned a_mask[A_PASSES];
@@ -145,7 +146,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
         a_off[i] = (pb + cy * p.Win + cx) * ld + gch * 8;
         unsigned mk = 0;
         for (int t = 0; t < ntap; ++t) {
-          const int iy = cy + (pad ? t / 3 - 1 : 0), ix = cx + (pad ? t % 3 - 1 : 0);
+          const int iy = cy + (k3 ? t / 3 - pad : 0), ix = cx + (k3 ? t % 3 - pad : 0);
           if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mk |= 1u << t;
         }
         a_mask[i] = mk;
@@ -167,7 +168,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   // K order is chunk-major: k-tile kt = (64-channel chunk, tap), tap fastest (see pack_conv_kernel)
   int ld_tap = kt_begin % ntap;
   int ld_cin0 = (kt_begin / ntap) * BK;
-  int ld_ky = pad ? ld_tap / 3 : 0, ld_kx = pad ? ld_tap - 3 * (ld_tap / 3) : 0;
+  int ld_ky = k3 ? ld_tap / 3 : 0, ld_kx = k3 ? ld_tap - 3 * (ld_tap / 3) : 0;
 
   auto issue_loads = [&](int stage) {
     const bool live = ld_kt < kt_end;             // past the end (NS > 2): dummy loads from the zero page

@@ -13,7 +13,12 @@ namespace {
 
 // pixels per statistics block: small at the low-resolution levels, where the parallelism has to come from
 // many tiny blocks (the kernels are latency-, not bandwidth-bound there)
-static inline int gn_chunk(int HW) { return HW >= 2048 ? 16 : (HW >= 512 ? 8 : 4); }
+// pixels per statistics block: small at UNet sizes (many blocks for a short kernel); at VAE sizes (HW >= 16K) ~16K elements
+// per block, which also bounds the number of atomics that land on one accumulator word
+static inline int gn_chunk(int HW, int C) {
+  if (HW >= 16384) { int px = 16; while (px * C < 16384 && px < 256) px *= 2; return px; }
+  return HW >= 2048 ? 16 : (HW >= 512 ? 8 : 4);
+}
 constexpr int GN_MAXC = 2560 * 2;
 
 __device__ __forceinline__ f32x4 load_cat4(const float* x0, const float* x1, int c0, int c1, size_t pix, int c) {
@@ -27,7 +32,7 @@ __device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp
 }
 
 // Statistics: every block reduces its pixel chunk to one {sum, sumsq} per group and adds them, as fixed-point
-// int64 (sum * 2^32, sumsq * 2^28), into one of GN_SLOTS accumulator slots of (b, g).  Integer addition is associative:
+// int64 words (integer part + 2^-40 fraction), into one of GN_SLOTS accumulator slots of (b, g).  Integer addition is associative:
 // the totals are bit-identical whatever the block order, with no finalize kernel and no inter-block ordering.
 // Threads are laid out as [pixel lane][channel quad] so (almost) all 256 threads have loads in flight even at C = 320.
 __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk, int chunk_px) {
@@ -74,21 +79,23 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
       for (int l = 1; l < PL; ++l) { a += lsum[l - 1][c]; q += lsq[l - 1][c]; }
       s += a; ss += q;
     }
-    unsigned long long* dst = (unsigned long long*)p.acc + ((size_t)(b * 32 + tid) * GN_SLOTS + (chunk & (GN_SLOTS - 1))) * 2;
-    atomicAdd(dst, (unsigned long long)__double2ll_rn((double)s * 4294967296.0));
-    atomicAdd(dst + 1, (unsigned long long)__double2ll_rn((double)ss * 268435456.0));
+    unsigned long long* dst = (unsigned long long*)p.acc + ((size_t)(b * 32 + tid) * GN_SLOTS + (chunk & (GN_SLOTS - 1))) * GN_WORDS;
+    gn_acc_add(dst, s);
+    gn_acc_add(dst + 2, ss);
   }
 }
 
 // fold the GN_SLOTS accumulators of (b, g): called by 8 consecutive lanes (sub = lane & 7), result valid on sub == 0
 __device__ __forceinline__ void gn_fold(const long long* acc, int b, int g, int sub, double n, float eps, float* mean,
                                         float* rstd) {
-  const long long* src = acc + ((size_t)(b * 32 + g) * GN_SLOTS + sub) * 2;
-  long long s = src[0], ss = src[1];
+  const long long* src = acc + ((size_t)(b * 32 + g) * GN_SLOTS + sub) * GN_WORDS;
+  long long s = src[0], sl = src[1], ss = src[2], ssl = src[3];
 #pragma unroll
-  for (int o = 4; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }
-  const double m = (double)s * (1.0 / 4294967296.0) / n;
-  double var = (double)ss * (1.0 / 268435456.0) / n - m * m;
+  for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {
+    s += __shfl_xor(s, o); sl += __shfl_xor(sl, o); ss += __shfl_xor(ss, o); ssl += __shfl_xor(ssl, o);
+  }
+  const double m = gn_acc_value(s, sl) / n;
+  double var = gn_acc_value(ss, ssl) / n - m * m;
   if (var < 0.0) var = 0.0;
   *mean = (float)m;
   *rstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -195,7 +202,7 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   SDMI_CHECK(p.acc != nullptr && p.gamma && p.beta && p.x0, "GroupNorm: missing pointer");
   SDMI_CHECK(p.c1 == 0 || p.x1 != nullptr, "GroupNorm: second source missing");
   SDMI_CHECK(C / 32 >= 2, "GroupNorm: at least 2 channels per group");
-  const int chunk_px = gn_chunk(p.HW);
+  const int chunk_px = gn_chunk(p.HW, C);
   const int nchunk = cdiv(p.HW, chunk_px);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);

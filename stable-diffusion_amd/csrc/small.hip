@@ -224,6 +224,64 @@ static int get_freqs(int half, const float** out) {
   return 0;
 }
 
+
+// ---- first-stage (VAE) helpers ---------------------------------------------------------------------------------------
+// 1x1 conv on a few channels, NCHW fp32 -> NCHW fp32, input optionally pre-scaled:
+// post_quant_conv / quant_conv (ldm/models/autoencoder.py:302-303) and the 1/scale_factor of decode_first_stage
+constexpr int PW_MAXC = 16;
+__global__ void __launch_bounds__(256) pointwise_nchw_kernel(const float* x, const float* w, const float* bias, float* out,
+                                                             int B, int Cin, int Cout, int HW, float in_scale) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (int64_t)B * HW) return;
+  const int b = (int)(idx / HW), pix = (int)(idx - (int64_t)b * HW);
+  float v[PW_MAXC];
+#pragma unroll
+  for (int c = 0; c < PW_MAXC; ++c) v[c] = (c < Cin) ? x[((size_t)b * Cin + c) * HW + pix] * in_scale : 0.f;
+  for (int o = 0; o < Cout; ++o) {
+    float acc = bias ? bias[o] : 0.f;
+#pragma unroll
+    for (int c = 0; c < PW_MAXC; ++c)
+      if (c < Cin) acc += w[o * Cin + c] * v[c];
+    out[((size_t)b * Cout + o) * HW + pix] = acc;
+  }
+}
+
+// P[r][c] = softmax_c(S[r][c] * scale), fp32 in -> fp16 out; one block per row (AttnBlock, model.py:186-187)
+__global__ void __launch_bounds__(256) softmax_rows_kernel(const float* S, f16* P, int cols, int lds, int ldp, float scale) {
+  __shared__ float red[8];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = S + (size_t)blockIdx.x * lds;
+  f16* dst = P + (size_t)blockIdx.x * ldp;
+  float mx = -INFINITY;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const f32x4 v = *(const f32x4*)(src + c);
+    mx = fmaxf(fmaxf(mx, fmaxf(v[0], v[1])), fmaxf(v[2], v[3]));
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if (lane == 0) red[wave] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale;
+  float sum = 0.f;
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const f32x4 v = *(const f32x4*)(src + c);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sum += __expf(v[j] * scale - mx);
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o);
+  if (lane == 0) red[4 + wave] = sum;
+  __syncthreads();
+  const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+  for (int c = tid * 4; c < cols; c += 1024) {
+    const f32x4 v = *(const f32x4*)(src + c);
+    f16x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (f16)(__expf(v[j] * scale - mx) * inv);
+    *(f16x4*)(dst + c) = o;
+  }
+}
+
 int launch_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, hipStream_t s) {
   SDMI_CHECK((t_i64 != nullptr) != (t_f32 != nullptr), "exactly one of int64 / fp32 timesteps");
   const float* freqs = nullptr;
@@ -259,6 +317,25 @@ int launch_conv_out(const float* h, const float* w, const float* bias, float* ou
   SDMI_CHECK(Cout <= CO_MAXN && Cin % 4 == 0, "conv_out: out_channels <= 8, Cin % 4 == 0");
   ProfScope ps("conv_out_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
   hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+
+int launch_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int HW,
+                          float in_scale, hipStream_t s) {
+  SDMI_CHECK(Cin >= 1 && Cin <= PW_MAXC && Cout >= 1, "pointwise conv: 1 <= Cin <= 16");
+  const int64_t total = (int64_t)B * HW;
+  hipLaunchKernelGGL(pointwise_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, out, B, Cin,
+                     Cout, HW, in_scale);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_softmax_rows(const float* S, f16* P, int rows, int cols, int lds, int ldp, float scale, hipStream_t s) {
+  SDMI_CHECK(cols % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0 && rows >= 1, "softmax rows: cols % 4");
+  ProfScope ps("softmax_rows", 0.0, (double)rows * cols * 6.0, s);
+  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, P, cols, lds, ldp, scale);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -193,6 +193,28 @@ int UNet::build(const sdmi_unet_cfg& c) {
   return 0;
 }
 
+int DevStage::acquire(const float* ptr, int64_t numel, hipStream_t stream) {
+  dptr = ptr;
+  hipPointerAttribute_t attr;
+  hipError_t e = hipPointerGetAttributes(&attr, ptr);
+  const bool on_device = (e == hipSuccess) && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
+  if (e != hipSuccess) (void)hipGetLastError();
+  if (!on_device) {
+    SDMI_HIP_OK(hipMalloc((void**)&staged, numel * sizeof(float)));
+    SDMI_HIP_OK(hipMemcpyAsync(staged, ptr, numel * sizeof(float), hipMemcpyHostToDevice, stream));
+    dptr = staged;
+  }
+  return 0;
+}
+int DevStage::release(hipStream_t stream) {
+  if (staged) {
+    SDMI_HIP_OK(hipStreamSynchronize(stream));
+    (void)hipFree(staged);
+    staged = nullptr;
+  }
+  return 0;
+}
+
 UNet::~UNet() {
   for (void* p : owned_) (void)hipFree(p);
 }
@@ -214,18 +236,9 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
     SDMI_CHECK(shape[i] == s.shape[i], std::string("shape mismatch for ") + key);
     numel *= shape[i];
   }
-  // host pointer? stage it on the device first
-  const float* dptr = ptr;
-  float* staged = nullptr;
-  hipPointerAttribute_t attr;
-  hipError_t e = hipPointerGetAttributes(&attr, ptr);
-  bool on_device = (e == hipSuccess) && (attr.type == hipMemoryTypeDevice || attr.type == hipMemoryTypeManaged);
-  if (e != hipSuccess) (void)hipGetLastError();
-  if (!on_device) {
-    SDMI_HIP_OK(hipMalloc((void**)&staged, numel * sizeof(float)));
-    SDMI_HIP_OK(hipMemcpyAsync(staged, ptr, numel * sizeof(float), hipMemcpyHostToDevice, stream));
-    dptr = staged;
-  }
+  DevStage st;
+  if (st.acquire(ptr, numel, stream)) return -1;
+  const float* dptr = st.dptr;
   int rc = 0;
   switch (s.kind) {
     case W_F32:
@@ -281,10 +294,7 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
       break;
     }
   }
-  if (staged) {
-    SDMI_HIP_OK(hipStreamSynchronize(stream));
-    (void)hipFree(staged);
-  }
+  if (st.release(stream)) return -1;
   if (rc) return rc;
   s.set = true;
   finalized_ = false;
@@ -306,76 +316,10 @@ int UNet::finalize() {
 // ------------------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------------------
-struct Arena {
-  char* base = nullptr; size_t cap = 0, off = 0, peak = 0; bool dry = false; bool overflow = false;
-  void* alloc(size_t bytes) {
-    const size_t a = (off + 255) & ~(size_t)255;
-    off = a + bytes;
-    peak = std::max(peak, off);
-    if (dry) return (void*)(uintptr_t)(a + 4096);   // fake non-null address; never dereferenced
-    if (off > cap) { overflow = true; return base; }
-    return base + a;
-  }
-};
-
-struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
-
-struct Fwd {
-  UNet* u; hipStream_t s; bool dry; int B, Lctx;
-  Arena persist, scratch;
-  long long* gn_acc = nullptr;   // GN_MAX_CALLS regions of gn_acc_words(B) int64, zeroed once per forward
-  int gn_calls = 0;
-  long long* next_gn_acc() {
-    if (gn_calls >= GN_MAX_CALLS) { ok(fail("more GroupNorm calls than accumulator regions")); return gn_acc; }
-    return gn_acc + (size_t)(gn_calls++) * gn_acc_words(B);
-  }
-  long long* last_gn_acc() const { return gn_acc + (size_t)(gn_calls - 1) * gn_acc_words(B); }
-  float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
+struct Fwd : FwdBase {
+  UNet* u; int Lctx;
   float* emb_all = nullptr;     // [B][emb_total]
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
-  int rc = 0;
-
-  template <class T> T* P(size_t n) { return (T*)persist.alloc(n * sizeof(T)); }
-  template <class T> T* S(size_t n) { return (T*)scratch.alloc(n * sizeof(T)); }
-  void ok(int r) { if (r && !rc) rc = r; }
-
-  void gemm(IGemmParams& p) {
-    p.zero_page = u->zero_;
-    p.splitk_ws = splitk_ws; p.splitk_ws_floats = splitk_ws_floats;
-    if (!dry && !rc) ok(launch_igemm(p, IGemmTune(), s));
-  }
-  // dense [M][K] x W[N][K]^T
-  IGemmParams dense(const f16* a, int M, int K, const f16* w, int N, int rows_per_batch) {
-    IGemmParams p;
-    p.a0 = a; p.c0 = K; p.lda0 = K;
-    p.B = M / rows_per_batch; p.Hin = p.Hout = rows_per_batch; p.Win = p.Wout = 1;
-    p.ksize = 1; p.w = w; p.M = M; p.N = N; p.K = K; p.splitk = 0;
-    return p;
-  }
-  IGemmParams conv3(const f16* a, int C, int Hin, int Win, int Hout, int Wout, int stride, int up, const f16* w, int N) {
-    IGemmParams p;
-    p.a0 = a; p.c0 = C; p.lda0 = C;
-    p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
-    p.ksize = 3; p.stride = stride; p.up = up; p.w = w; p.M = B * Hout * Wout; p.N = N; p.K = 9 * C; p.splitk = 0;
-    return p;
-  }
-  // 1x1 conv on split-fp16 operands: A' = [hi | lo | hi], W' = [hi | hi | lo] (packed W_SPLIT3) when precise
-  IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch) {
-    IGemmParams p = dense(hi, M, K, w, N, rows_per_batch);
-    if (u->precise_1x1_) {
-      p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K;
-    }
-    return p;
-  }
-  void groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
-                 float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr) {
-    GroupNormParams g;
-    g.x0 = x0.p; g.c0 = x0.C;
-    if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
-    g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
-    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.acc = next_gn_acc();
-    if (!dry && !rc) ok(launch_groupnorm(g, s));
-  }
 
   void gn_stats_only(const Act& x0, const Act* x1, float eps, f16* raw, f16* raw_lo, const float* gamma, const float* beta) {
     GroupNormParams g;
@@ -397,7 +341,7 @@ struct Fwd {
     const bool fused = u->fuse_gn_conv_ && H * W >= 1024 && conv3gn_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout) &&
                        conv3gn_supported(B, H, W, Cout, 0, Cout);
     f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
-    f16* raw_lo = (Cin != Cout && u->precise_1x1_) ? S<f16>((size_t)M * Cin) : nullptr;
+    f16* raw_lo = (Cin != Cout && precise_1x1) ? S<f16>((size_t)M * Cin) : nullptr;
     float* h = S<float>((size_t)M * Cout);
     Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
     Act hact; hact.p = h; hact.C = Cout; hact.H = H; hact.W = W;
@@ -462,7 +406,7 @@ struct Fwd {
     const float scale = 1.0f / sqrtf((float)L.dh);
     const size_t mark = scratch.off;
     f16* xn = S<f16>((size_t)M * C);
-    f16* xn_lo = u->precise_1x1_ ? S<f16>((size_t)M * C) : nullptr;
+    f16* xn_lo = precise_1x1 ? S<f16>((size_t)M * C) : nullptr;
     groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
     float* t = S<float>((size_t)M * C);
     {
@@ -598,13 +542,13 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
   SDMI_CHECK(H % down == 0 && W % down == 0, "H and W must be divisible by 2^(levels-1) (the UNet's skip concat requires it)");
 
   Fwd f;
-  f.u = this; f.s = stream; f.dry = dry; f.B = B; f.Lctx = Lctx;
+  f.u = this; f.s = stream; f.dry = dry; f.B = B; f.Lctx = Lctx; f.zero = zero_; f.precise_1x1 = precise_1x1_;
   // first pass (always dry) sizes the two arenas; the persist arena sits in front of the scratch arena
   int64_t persist_bytes = 0, scratch_bytes = 0;
   for (int pass = (dry ? 0 : 0); pass < 2; ++pass) {
     const bool d = (pass == 0) ? true : false;
     if (pass == 1 && dry) break;
-    f.dry = d; f.rc = 0; f.gn_calls = 0;
+    f.dry = d; f.rc = 0;
     f.persist = Arena(); f.scratch = Arena();
     f.persist.dry = f.scratch.dry = d;
     if (!d) {
@@ -616,10 +560,7 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       if (ensure_ctx_cache(B, Lctx)) return -1;
     }
     const int mc = cfg_.model_channels;
-    f.gn_acc = f.P<long long>((size_t)GN_MAX_CALLS * gn_acc_words(B));
-    if (!d) SDMI_HIP_OK(hipMemsetAsync(f.gn_acc, 0, (size_t)GN_MAX_CALLS * gn_acc_words(B) * sizeof(long long), stream));
-    f.splitk_ws_floats = (int64_t)12 << 20;            // 48 MB of fp32 slabs (largest user: 8 x 512 x 1280)
-    f.splitk_ws = f.P<float>((size_t)f.splitk_ws_floats);
+    if (f.begin_pass((int64_t)12 << 20)) return -1;    // 48 MB of fp32 split-K slabs (largest user: 8 x 512 x 1280)
     f16* ctx16 = f.P<f16>((size_t)B * Lctx * cfg_.context_dim);
     const bool have_ctx = (ctx != nullptr) || d;
     if (have_ctx) {

@@ -9,6 +9,97 @@
 
 namespace sdmi {
 
+// bump allocator over a caller-provided workspace; `dry` only measures
+struct Arena {
+  char* base = nullptr; size_t cap = 0, off = 0, peak = 0; bool dry = false; bool overflow = false;
+  void* alloc(size_t bytes) {
+    const size_t a = (off + 255) & ~(size_t)255;
+    off = a + bytes;
+    peak = std::max(peak, off);
+    if (dry) return (void*)(uintptr_t)(a + 4096);   // fake non-null address; never dereferenced
+    if (off > cap) { overflow = true; return base; }
+    return base + a;
+  }
+};
+
+struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
+
+// state and helpers shared by the executors (UNet forward, first-stage encode / decode): arenas, GroupNorm accumulator
+// regions, split-K slabs and the igemm / GroupNorm launch wrappers
+struct FwdBase {
+  hipStream_t s = nullptr; bool dry = false; int B = 1;
+  const f16* zero = nullptr;      // zero page for out-of-image conv taps
+  bool precise_1x1 = true;        // 1x1 convs on the residual stream as 3-pass split-fp16 GEMMs
+  Arena persist, scratch;
+  long long* gn_acc = nullptr;   // GN_MAX_CALLS regions of gn_acc_words(B) int64, zeroed once per forward
+  int gn_calls = 0;
+  float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
+  int rc = 0;
+
+  template <class T> T* P(size_t n) { return (T*)persist.alloc(n * sizeof(T)); }
+  template <class T> T* S(size_t n) { return (T*)scratch.alloc(n * sizeof(T)); }
+  void ok(int r) { if (r && !rc) rc = r; }
+  long long* next_gn_acc() {
+    if (gn_calls >= GN_MAX_CALLS) { ok(fail("more GroupNorm calls than accumulator regions")); return gn_acc; }
+    return gn_acc + (size_t)(gn_calls++) * gn_acc_words(B);
+  }
+  long long* last_gn_acc() const { return gn_acc + (size_t)(gn_calls - 1) * gn_acc_words(B); }
+  // allocate + zero the accumulator regions and the split-K slabs (call once per pass, before any layer)
+  int begin_pass(int64_t splitk_floats) {
+    gn_calls = 0;
+    gn_acc = P<long long>((size_t)GN_MAX_CALLS * gn_acc_words(B));
+    if (!dry) SDMI_HIP_OK(hipMemsetAsync(gn_acc, 0, (size_t)GN_MAX_CALLS * gn_acc_words(B) * sizeof(long long), s));
+    splitk_ws_floats = splitk_floats;
+    splitk_ws = P<float>((size_t)splitk_floats);
+    return 0;
+  }
+
+  void gemm(IGemmParams& p) {
+    p.zero_page = zero;
+    p.splitk_ws = splitk_ws; p.splitk_ws_floats = splitk_ws_floats;
+    if (!dry && !rc) ok(launch_igemm(p, IGemmTune(), s));
+  }
+  // dense [M][K] x W[N][K]^T
+  IGemmParams dense(const f16* a, int M, int K, const f16* w, int N, int rows_per_batch) {
+    IGemmParams p;
+    p.a0 = a; p.c0 = K; p.lda0 = K;
+    p.B = M / rows_per_batch; p.Hin = p.Hout = rows_per_batch; p.Win = p.Wout = 1;
+    p.ksize = 1; p.w = w; p.M = M; p.N = N; p.K = K; p.splitk = 0;
+    return p;
+  }
+  IGemmParams conv3(const f16* a, int C, int Hin, int Win, int Hout, int Wout, int stride, int up, const f16* w, int N) {
+    IGemmParams p;
+    p.a0 = a; p.c0 = C; p.lda0 = C;
+    p.B = B; p.Hin = Hin; p.Win = Win; p.Hout = Hout; p.Wout = Wout;
+    p.ksize = 3; p.stride = stride; p.up = up; p.w = w; p.M = B * Hout * Wout; p.N = N; p.K = 9 * C; p.splitk = 0;
+    return p;
+  }
+  // 1x1 conv on split-fp16 operands: A' = [hi | lo | hi], W' = [hi | hi | lo] (packed W_SPLIT3) when precise
+  IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch) {
+    IGemmParams p = dense(hi, M, K, w, N, rows_per_batch);
+    if (precise_1x1) {
+      p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K;
+    }
+    return p;
+  }
+  void groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
+                 float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr) {
+    GroupNormParams g;
+    g.x0 = x0.p; g.c0 = x0.C;
+    if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
+    g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
+    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.acc = next_gn_acc();
+    if (!dry && !rc) ok(launch_groupnorm(g, s));
+  }
+};
+
+// host or device fp32 pointer -> device pointer (staged through a temporary device buffer when it is host memory)
+struct DevStage {
+  const float* dptr = nullptr; float* staged = nullptr;
+  int acquire(const float* ptr, int64_t numel, hipStream_t stream);
+  int release(hipStream_t stream);
+};
+
 enum LayerKind { L_CONV_IN, L_RES, L_ATTN, L_DOWN, L_UP };
 enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B, W_SPLIT3 };
 

@@ -29,6 +29,23 @@ def randomize_(unet, seed=0):
     return unet
 
 
+@torch.no_grad()
+def randomize_vae_(vae, seed=0):
+    """In-place unit-gain init of an AutoencoderKLHIP (or anything with the same parameter names)."""
+    dev = next(vae.parameters()).device
+    g = torch.Generator(device=dev).manual_seed(seed)
+    for name, p in vae.named_parameters():
+        if name.endswith('.weight') and p.dim() >= 2:
+            p.copy_(torch.randn(p.shape, generator=g, device=dev) / math.sqrt(p[0].numel()))
+        elif name.endswith('.weight'):
+            p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g, device=dev))
+        else:
+            p.copy_(0.02 * torch.randn(p.shape, generator=g, device=dev))
+    if hasattr(vae, 'mark_dirty'):
+        vae.mark_dirty()
+    return vae
+
+
 def synthetic_state_dict(unet_kwargs, seed=0):
     """CPU state_dict (reference key names) of a seeded random SD-v1-architecture UNet."""
     from .unet import UNetModelHIP
@@ -41,3 +58,6 @@ SD_V1_UNET_KWARGS = dict(image_size=32, in_channels=4, out_channels=4, model_cha
                          attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
                          use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,
                          legacy=False)   # configs/stable-diffusion/v1-inference.yaml:29-44
+
+SD_V1_VAE_DDCONFIG = dict(double_z=True, z_channels=4, resolution=256, in_channels=3, out_ch=3, ch=128,
+                          ch_mult=[1, 2, 4, 4], num_res_blocks=2, attn_resolutions=[], dropout=0.0)   # yaml:51-65

@@ -42,7 +42,8 @@ def cast_f16(x, want_lo=False):
 
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
-          residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None):
+          residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None,
+          asym_pad=0):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
     d = _lib.IGemmDesc()
     d.a0 = a0.data_ptr(); d.c0 = a0.shape[1]; d.lda0 = a0.stride(0)
@@ -65,6 +66,7 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
             d.seg_dst[i] = t.data_ptr(); d.seg_kind[i] = kind
         d.heads, d.dh, d.ntok, d.ntok_pad, d.segC = heads['heads'], heads['dh'], heads['ntok'], heads['ntok_pad'], heads['segC']
     d.splitk, d.tile, d.dma = splitk, tile, dma
+    d.asym_pad = asym_pad
     ws = None
     if splitk != 1:
         M = B * Hout * Wout
@@ -144,6 +146,22 @@ def conv_out(h, w, b, B, H, W):
     out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=h.device)
     _lib.check(_lib.load().sdmi_k_conv_out(h.data_ptr(), wp.data_ptr(), b.data_ptr(), out.data_ptr(), B, H, W, Cin, Cout, _s()))
     return out
+
+
+def pointwise_nchw(x, w, b, in_scale=1.0):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    out = torch.empty((B, Cout, H, W), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sdmi_k_pointwise_nchw(x.data_ptr(), w.contiguous().data_ptr(), _lib.ptr(b), out.data_ptr(), B,
+                                                 Cin, Cout, H * W, float(in_scale), _s()))
+    return out
+
+
+def softmax_rows(S, scale):
+    rows, cols = S.shape
+    P = torch.empty((rows, cols), dtype=torch.float16, device=S.device)
+    _lib.check(_lib.load().sdmi_k_softmax_rows(S.data_ptr(), P.data_ptr(), rows, cols, float(scale), _s()))
+    return P
 
 
 def sampler_step(eps_model, cfg, scale, x, mode, old, a_t, a_prev, sigma, s1m, noise=None):

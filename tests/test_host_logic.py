@@ -20,21 +20,22 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 1
+    assert lib.sdmi_abi_version() == 2
     for name in declared:
         assert hasattr(lib, name)
 
 
 def test_ctypes_struct_layout_matches_header():
-    """sizeof / field order of the two ABI structs as the C compiler sees them."""
+    """sizeof / field order of the ABI structs as the C compiler sees them."""
     import ctypes as C
     from stable_diffusion_amd import _lib
     src = r'''
 #include <stdio.h>
 #include <stddef.h>
 #include "sdmi.h"
-int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg), offsetof(sdmi_unet_cfg, context_dim),
- sizeof(sdmi_igemm_desc), offsetof(sdmi_igemm_desc, w), offsetof(sdmi_igemm_desc, seg_dst), offsetof(sdmi_igemm_desc, dma)); }
+int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg), offsetof(sdmi_unet_cfg, context_dim),
+ sizeof(sdmi_igemm_desc), offsetof(sdmi_igemm_desc, w), offsetof(sdmi_igemm_desc, seg_dst), offsetof(sdmi_igemm_desc, dma),
+ offsetof(sdmi_igemm_desc, asym_pad), sizeof(sdmi_vae_cfg), offsetof(sdmi_vae_cfg, embed_dim)); }
 '''
     d = os.path.join(ROOT, 'stable-diffusion_amd', 'build')
     os.makedirs(d, exist_ok=True)
@@ -44,7 +45,8 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg), offsetof(
     subprocess.run(['gcc', '-I', os.path.join(ROOT, 'include'), c, '-o', exe], check=True)
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(_lib.UNetCfg), _lib.UNetCfg.context_dim.offset, C.sizeof(_lib.IGemmDesc), _lib.IGemmDesc.w.offset,
-            _lib.IGemmDesc.seg_dst.offset, _lib.IGemmDesc.dma.offset]
+            _lib.IGemmDesc.seg_dst.offset, _lib.IGemmDesc.dma.offset, _lib.IGemmDesc.asym_pad.offset,
+            C.sizeof(_lib.VaeCfg), _lib.VaeCfg.embed_dim.offset]
     assert got == want
 
 
@@ -65,6 +67,24 @@ def test_unet_shim_has_reference_parameter_names():
     specs = h.weight_specs()
     assert {k: tuple(s) for k, s in specs} == {k: tuple(s) for k, s, _ in param_specs(SD_V1)}
     assert len(specs) == 686
+
+
+def test_vae_shim_has_reference_parameter_names():
+    """AutoencoderKLHIP.state_dict() keys/shapes == AutoencoderKL's (oracle.vae_ref.vae_param_specs is pinned to the
+    reference Encoder / Decoder by make_golden_vae's strict load), so the first_stage_model.* part of a checkpoint loads."""
+    from oracle.vae_ref import SD_VAE, TINY_VAE, vae_param_specs
+    from stable_diffusion_amd import AutoencoderKLHIP
+    m = AutoencoderKLHIP(TINY_VAE.ddconfig(), {'target': 'torch.nn.Identity'}, TINY_VAE.embed_dim)
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert mine == {k: tuple(s) for k, s, _ in vae_param_specs(TINY_VAE)}
+    from stable_diffusion_amd.vae import _VaeHandle, make_vae_cfg
+    for parts, enc, dec in ((1, False, True), (2, True, False), (3, True, True)):
+        specs = _VaeHandle(make_vae_cfg(SD_VAE.ddconfig(), SD_VAE.embed_dim), parts).weight_specs()
+        assert {k: tuple(s) for k, s in specs} == {k: tuple(s) for k, s, _ in vae_param_specs(SD_VAE, enc, dec)}
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m.decode(torch.zeros(1, 4, 8, 8))
+    with pytest.raises(NotImplementedError):
+        AutoencoderKLHIP(dict(TINY_VAE.ddconfig(), attn_resolutions=[16]), None, 4)
 
 
 def test_shim_refuses_cpu_tensors_and_foreign_configs():

@@ -281,6 +281,54 @@ def test_time_embedding_path():
         assert K.report(f'small_linear silu{silu}', outl, refl, 2e-5) < 2e-5
 
 
+@pytest.mark.parametrize('tile', [0, 2, 3])
+@pytest.mark.parametrize('B,H,W,C,N', [(2, 12, 12, 64, 128), (1, 6, 10, 128, 64)])
+def test_igemm_conv_stride2_asym_pad(tile, B, H, W, C, N):
+    """VAE Downsample (ldm/modules/diffusionmodules/model.py:72-76): F.pad(x,(0,1,0,1)) + conv3x3(stride 2, padding 0)."""
+    g = _g(31)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(C * 9))
+    x = a.float().reshape(B, H, W, C).permute(0, 3, 1, 2)
+    ref = F.conv2d(F.pad(x, (0, 1, 0, 1)), w.float(), None, stride=2, padding=0)
+    Hout, Wout = ref.shape[2], ref.shape[3]
+    assert (Hout, Wout) == (H // 2, W // 2)
+    bias = torch.randn(N, generator=g)
+    out32 = torch.full((B * Hout * Wout, N), float('nan'), device=DEV)
+    K.igemm(a.to(DEV), K.pack_conv_weight(w.float().to(DEV)), N, B, H, W, Hout, Wout, 3, 2, 0, bias=bias.to(DEV),
+            out_f32=out32, tile=tile, asym_pad=1)
+    torch.cuda.synchronize()
+    assert K.report(f'igemm asym-pad s2 tile{tile}', out32, _nhwc(ref) + bias[None], 2e-4) < 2e-4
+
+
+def test_vae_small_kernels():
+    g = _g(32)
+    x = torch.randn(2, 4, 9, 7, generator=g)
+    w = torch.randn(8, 4, generator=g)
+    b = torch.randn(8, generator=g)
+    ref = F.conv2d(x * 3.0, w[:, :, None, None], b)
+    out = K.pointwise_nchw(x.to(DEV), w.to(DEV), b.to(DEV), in_scale=3.0)
+    assert K.report('pointwise_nchw', out, ref, 1e-5) < 1e-5
+    S = torch.randn(37, 4096, generator=g) * 40
+    ref = torch.softmax(S * 0.044, dim=1)
+    P = K.softmax_rows(S.to(DEV), 0.044)
+    # fp16 output of values <= 1: half-ulp 2.4e-4 relative
+    assert K.report('softmax_rows', P, ref, 5e-4) < 5e-4
+    assert (P.float().sum(1) - 1).abs().max().item() < 2e-3
+
+
+def test_groupnorm_large_map_and_range():
+    """VAE-sized map (HW = 256*256, C = 128) and large-magnitude activations: the fixed-point statistics must neither
+    lose precision nor wrap."""
+    g = _g(33)
+    B, HW, C = 1, 256 * 256, 128
+    x = torch.randn(B, HW, C, generator=g) * 300.0 + 1000.0
+    gamma = 1 + 0.1 * torch.randn(C, generator=g); beta = 0.1 * torch.randn(C, generator=g)
+    ref = F.group_norm(x.permute(0, 2, 1).double(), 32, gamma.double(), beta.double(), eps=1e-6).permute(0, 2, 1).float()
+    out = K.groupnorm(x.to(DEV), None, gamma.to(DEV), beta.to(DEV), 1e-6, 0, want=('f32',))['f32']
+    # mean ~1000 with std 300: fp32 cancellation in (x - mean) * rstd costs ~1e-4 relative of |x|/std
+    assert K.report('groupnorm 256x256x128 offset', out, ref, 2e-3) < 2e-3
+
+
 def test_conv_in_out():
     g = _g(12)
     B, H, W = 2, 9, 12

@@ -82,3 +82,44 @@ def test_oracle_samplers_match_reference_golden(golden_dir):
     assert (z - torch.from_numpy(G['img2img_z'])).abs().max().item() < 1e-6
     out = samplers_ref.ddim_decode(_stub, ac, 50, z, c, 37, 5.0, uc)
     assert (out - torch.from_numpy(G['img2img_out'])).abs().max().item() < 1e-6
+
+
+# ---- first stage: oracle/vae_ref.py against the reference Encoder / Decoder goldens -----------------
+@pytest.mark.parametrize('case', ['tiny_8x8', 'tiny_8x24', 'small_16x16', 'sd_8x8'])
+def test_oracle_vae_decode_matches_reference_golden(case, golden_dir):
+    from oracle import vae_ref
+    cfgs = {'tiny': vae_ref.TINY_VAE, 'small': vae_ref.SMALL_VAE, 'sd': vae_ref.SD_VAE}
+    z = np.load(os.path.join(golden_dir, f'vae_dec_{case}.npz'))
+    cfg = cfgs[str(z['cfg'])]
+    sd = vae_ref.make_vae_state_dict(cfg, int(z['weight_seed']), encoder=False)
+    lat = vae_ref.make_vae_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']))
+    img = vae_ref.vae_decode(sd, cfg, lat)
+    ref = torch.from_numpy(z['out'])
+    assert img.shape == ref.shape and float(ref.abs().max()) > 1.0
+    assert (img - ref).abs().max().item() < 5e-5
+
+
+def test_vae_state_dict_is_seed_stable():
+    """a decoder-only / encoder-only dict holds the same tensors as the full one (the goldens were made from the full one)."""
+    from oracle import vae_ref
+    full = vae_ref.make_vae_state_dict(vae_ref.TINY_VAE, 0)
+    assert len(full) == 124
+    dec = vae_ref.make_vae_state_dict(vae_ref.TINY_VAE, 0, encoder=False)
+    enc = vae_ref.make_vae_state_dict(vae_ref.TINY_VAE, 0, decoder=False)
+    assert len(dec) + len(enc) == 124
+    assert all(torch.equal(v, full[k]) for k, v in list(dec.items()) + list(enc.items()))
+
+
+@pytest.mark.parametrize('case', ['tiny_32x32', 'tiny_16x48', 'sd_64x64'])
+def test_oracle_vae_encode_matches_reference_golden(case, golden_dir):
+    from oracle import vae_ref
+    cfgs = {'tiny': vae_ref.TINY_VAE, 'small': vae_ref.SMALL_VAE, 'sd': vae_ref.SD_VAE}
+    z = np.load(os.path.join(golden_dir, f'vae_enc_{case}.npz'))
+    cfg = cfgs[str(z['cfg'])]
+    sd = vae_ref.make_vae_state_dict(cfg, int(z['weight_seed']))
+    g = torch.Generator().manual_seed(int(z['input_seed']))
+    x = torch.rand(int(z['batch']), cfg.in_channels, int(z['h']), int(z['w']), generator=g) * 2 - 1
+    mom = vae_ref.vae_encode_moments(sd, cfg, x)
+    ref = torch.from_numpy(z['moments'])
+    assert mom.shape == ref.shape
+    assert (mom - ref).abs().max().item() < 5e-5
