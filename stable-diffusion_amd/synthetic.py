@@ -54,6 +54,15 @@ def synthetic_state_dict(unet_kwargs, seed=0):
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
+def synthetic_vae_state_dict(ddconfig, embed_dim=4, seed=0):
+    """CPU state_dict (reference key names: encoder.*, decoder.*, quant_conv.*, post_quant_conv.*) of a seeded random
+    first stage in the given architecture."""
+    from .vae import AutoencoderKLHIP
+    m = AutoencoderKLHIP(ddconfig, None, embed_dim)
+    randomize_vae_(m, seed)
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
 SD_V1_UNET_KWARGS = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320,
                          attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
                          use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,

@@ -164,3 +164,18 @@ def test_plugin_seam_against_the_real_reference():
     assert isinstance(mine, UNetModelHIP)
     assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == ref_keys
     assert len(ref_keys) == 686
+    # first stage: same mechanism (LatentDiffusion.instantiate_first_stage, ddpm.py:502-507); the reference class itself
+    # needs pytorch_lightning + taming (stand-ins installed above), its Encoder / Decoder are the real ones
+    fs_cfg = cfg['model']['params']['first_stage_config']
+    assert fs_cfg['target'] == 'ldm.models.autoencoder.AutoencoderKL'
+    import contextlib
+    import io
+    with torch.device('meta'), contextlib.redirect_stdout(io.StringIO()):
+        ref_vae = instantiate_from_config(fs_cfg)
+    ref_keys = {k: tuple(v.shape) for k, v in ref_vae.state_dict().items() if not k.startswith('loss.')}
+    with torch.device('meta'):
+        mine = instantiate_from_config(dict(fs_cfg, target='stable_diffusion_amd.vae.AutoencoderKLHIP'))
+    from stable_diffusion_amd import AutoencoderKLHIP
+    assert isinstance(mine, AutoencoderKLHIP)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == ref_keys
+    assert len(ref_keys) == 248

@@ -108,6 +108,33 @@ def test_igemm_splitk_inplace_residual(splitk, tile):
     assert torch.equal(out, out2)
 
 
+@pytest.mark.parametrize('B,H,W,C,N,splitk,tile', [(2, 16, 16, 1280, 1280, 4, 2), (2, 8, 8, 1280, 1280, 15, 2),
+                                                   (1, 5, 7, 256, 200, 3, 2), (2, 32, 32, 640, 640, 4, 3),
+                                                   (1, 5, 7, 256, 200, 2, 0)])
+def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile):
+    """SD-sized split-K convs (hundreds of blocks on all XCDs write slabs, the reduce kernel sums them in split order):
+    value, partial tiles, the per-batch row vector, and 4 bit-identical repeats."""
+    g = _g(77)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(9 * C))
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    resid = torch.randn(B * H * W, N, generator=g)
+    ref = _nhwc(_conv_ref(a, None, w, B, H, W, 3, 1, 0)) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    a_d, bias_d, rv_d, res_d = a.to(DEV), bias.to(DEV), rowvec.to(DEV), resid.to(DEV)
+    outs = []
+    for rep in range(4):
+        out = torch.full((B * H * W, N), float('nan'), device=DEV)
+        K.igemm(a_d, wp, N, B, H, W, H, W, 3, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=out,
+                splitk=splitk, tile=tile)
+        outs.append(out)
+    torch.cuda.synchronize()
+    assert K.report(f'igemm splitk-sd splitk{splitk} tile{tile} M{B * H * W} N{N}', outs[0], ref, 3e-4) < 3e-4
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
 def test_igemm_split_fp16_1x1():
     """3-pass split-fp16 1x1 conv (a_hi w_hi + a_lo w_hi + a_hi w_lo): fp32 operands to ~2^-22."""
     g = _g(9)

@@ -7,10 +7,12 @@ What this launcher does (nothing in the reference tree is edited or copied):
     (SURVEY.md 8b): omegaconf, pytorch_lightning, torchvision.utils, cv2, imwatermark, diffusers' safety checker,
     taming, clip, kornia; the HF `from_pretrained` calls (CLIP tokenizer / text model, safety feature extractor) get
     seeded random-init stand-ins because there is no network;
-  * `--ckpt synthetic[:seed]` makes `torch.load` return a seeded random UNet state_dict under the checkpoint's key names
-    (`model.diffusion_model.*`) -- there is no SD checkpoint in the environment; a real `--ckpt path` is loaded as usual;
+  * `--ckpt synthetic[:seed]` makes `torch.load` return a seeded random UNet + first-stage state_dict under the
+    checkpoint's key names (`model.diffusion_model.*`, `first_stage_model.*`) -- there is no SD checkpoint in the
+    environment; a real `--ckpt path` is loaded as usual;
   * `--hip`: writes a patched copy of the reference's `v1-inference.yaml` (only `unet_config.target` changed to
-    `stable_diffusion_amd.unet.UNetModelHIP`) to a temp file, passes it as `--config`, and swaps
+    `stable_diffusion_amd.unet.UNetModelHIP` and `first_stage_config.target` to
+    `stable_diffusion_amd.vae.AutoencoderKLHIP`) to a temp file, passes it as `--config`, and swaps
     `ldm.models.diffusion.plms.PLMSSampler` / `ddim.DDIMSampler` for the HIP samplers before the script imports them;
   * on a GPU-less host (BASELINE.json configs[0], the CPU plumbing check) it neutralises the hard-coded
     `.cuda()` / `torch.device("cuda")` uses (`txt2img.py:64`, `plms.py:18-22`); use `--precision full` there.
@@ -190,9 +192,12 @@ def patch_torch_load():
     def load(f, *a, **k):
         if isinstance(f, str) and f.startswith('synthetic'):
             seed = int(f.split(':')[1]) if ':' in f else 0
-            from stable_diffusion_amd.synthetic import SD_V1_UNET_KWARGS, synthetic_state_dict
-            sd = synthetic_state_dict(SD_V1_UNET_KWARGS, seed)
-            return {'state_dict': {'model.diffusion_model.' + key: v for key, v in sd.items()}}
+            from stable_diffusion_amd.synthetic import (SD_V1_UNET_KWARGS, SD_V1_VAE_DDCONFIG, synthetic_state_dict,
+                                                        synthetic_vae_state_dict)
+            sd = {'model.diffusion_model.' + key: v for key, v in synthetic_state_dict(SD_V1_UNET_KWARGS, seed).items()}
+            sd.update({'first_stage_model.' + key: v
+                       for key, v in synthetic_vae_state_dict(SD_V1_VAE_DDCONFIG, 4, seed).items()})
+            return {'state_dict': sd}
         return real(f, *a, **k)
     torch.load = load
 
@@ -224,6 +229,9 @@ def main():
         old = 'target: ldm.modules.diffusionmodules.openaimodel.UNetModel'
         assert old in text
         tmp = tempfile.NamedTemporaryFile('w', suffix='-mi355x.yaml', delete=False)
+        old_vae = 'target: ldm.models.autoencoder.AutoencoderKL'
+        assert old_vae in text
+        text = text.replace(old_vae, 'target: stable_diffusion_amd.vae.AutoencoderKLHIP')
         tmp.write(text.replace(old, 'target: stable_diffusion_amd.unet.UNetModelHIP'))
         tmp.close()
         rest = ['--config', tmp.name] + rest
