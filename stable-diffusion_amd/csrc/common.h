@@ -72,6 +72,11 @@ struct IGemmParams {
   const float* rowvec = nullptr; int ld_rowvec = 0;    // per-batch vector [B][ld_rowvec] added to every row of batch b
   const float* residual = nullptr; int ldr = 0;        // fp32 [M][ldr]
   float* out_f32 = nullptr; f16* out_f16 = nullptr; int ldo = 0;   // either / both
+  f16* out_lo = nullptr;                               // optional (plain mode): fp16(v - float(fp16(v))), the low half of a split-fp16 operand
+  // optional (plain mode): LayerNorm of the finished output rows -> ln_out fp16 [M][N] (needs out_f32 with ldo == N);
+  // launch_igemm issues the layernorm kernel after the GEMM (and its split-K reduce).  A reduce kernel with the
+  // LayerNorm folded in (one wave per row) was measured and was no faster than the two launches.
+  const float* ln_gamma = nullptr; const float* ln_beta = nullptr; f16* ln_out = nullptr; float ln_eps = 1e-5f;
   // EPI_HEADS: N = nseg * C, column n -> segment n / C, head (n % C) / dh, dd = n % dh
   //   seg_kind 0: row layout   dst[((b*heads + head) * ntok + tok) * dh + dd]
   //   seg_kind 1: transposed   dst[((b*heads + head) * dh + dd) * ntok_pad + tok]

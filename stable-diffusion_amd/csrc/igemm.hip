@@ -334,6 +334,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
               const float v = acc[i][j][r] + colv[j] + resv[r][j];
               if (p.out_f32) p.out_f32[ro + j * 32] = v;
               if (p.out_f16) p.out_f16[ro + j * 32] = (f16)v;
+              if (p.out_lo) p.out_lo[ro + j * 32] = (f16)(v - (float)(f16)v);
             }
           }
         }
@@ -365,6 +366,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
               if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
               if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
               if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
+              if (p.out_lo) p.out_lo[(size_t)m * p.ldo + n] = (f16)(v - (float)(f16)v);
             }
           }
         }
@@ -465,6 +467,12 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
   if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
   if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
   if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  if (p.out_lo) {
+    f16x4 lo;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo[j] = (f16)(v[j] - (float)(f16)v[j]);
+    *(f16x4*)(p.out_lo + (size_t)m * p.ldo + n) = lo;
+  }
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
@@ -499,7 +507,8 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   }
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
-  if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);
+  if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);     // (+ the LayerNorm launch when q.ln_out)
+  if (q.ln_out) return launch_layernorm(q.out_f32, q.ln_gamma, q.ln_beta, q.ln_out, q.M, q.N, q.ln_eps, stream);
   return 0;
 }
 
@@ -511,6 +520,8 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, nsplit);
   SDMI_HIP_OK(hipGetLastError());
+  ps2.end();
+  if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);
   return 0;
 }
 
@@ -530,6 +541,10 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   SDMI_CHECK((int64_t)p.B * p.Hin * p.Win * p.lda0 < (int64_t)1 << 31 && (int64_t)p.N * p.K < (int64_t)1 << 31,
              "tensor too large for 32-bit element offsets");
   if (p.mode == EPI_GEGLU) SDMI_CHECK(p.N % 64 == 0 && p.out_f16 != nullptr, "GEGLU needs N % 64 == 0 and an fp16 output");
+  if (p.ln_out)
+    SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && p.ldo == p.N && p.N % 4 == 0 && p.N <= 2560 && p.ln_gamma && p.ln_beta,
+               "LayerNorm post-op needs plain mode, an fp32 output with ldo == N <= 2560, gamma and beta");
+  if (p.out_lo) SDMI_CHECK(p.mode == EPI_PLAIN && p.ldo % 4 == 0, "out_lo needs plain mode");
   if (p.mode == EPI_HEADS) SDMI_CHECK(p.segC > 0 && p.dh > 0 && p.N % p.segC == 0 && p.N / p.segC <= 3, "bad head scatter");
 
   static const int env_dma = env_int("SDMI_IGEMM_DMA", 1);

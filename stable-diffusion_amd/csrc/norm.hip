@@ -37,13 +37,14 @@ __device__ __forceinline__ f16x4 lo_half(const f32x4 v) {   // fp16(v - float(fp
 // Threads are laid out as [pixel lane][channel quad] so (almost) all 256 threads have loads in flight even at C = 320.
 __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nchunk, int chunk_px) {
   __shared__ float csum[GN_MAXC], csq[GN_MAXC];
-  __shared__ float lsum[3][1024], lsq[3][1024];       // extra pixel lanes (PL <= 4) for C <= 1024
+  __shared__ float lsum[1024], lsq[1024];             // extra pixel lanes: (PL - 1) * C < 1024 floats
   const int b = blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
   const int C = p.c0 + p.c1;
   const int nq = C / 4;
   const int pix0 = chunk * chunk_px;
   const int npix = min(chunk_px, p.HW - pix0);
-  const int PL = (nq <= 256) ? min(4, 256 / nq) : 1;   // pixel lanes
+  // pixel lanes: 8 on first-stage-sized maps so all 256 threads load even at C = 128 (UNet-sized maps keep <= 4)
+  const int PL = (nq <= 256) ? min(p.HW >= 16384 ? 8 : 4, 256 / nq) : 1;
   const int pl = (nq <= 256) ? tid / nq : 0;
   const int q0 = (nq <= 256) ? tid - pl * nq : tid;
   if (pl < PL) {
@@ -65,7 +66,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
         for (int j = 0; j < 4; ++j) { csum[c + j] = s[j]; csq[c + j] = ss[j]; }
       } else {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) { lsum[pl - 1][c + j] = s[j]; lsq[pl - 1][c + j] = ss[j]; }
+        for (int j = 0; j < 4; ++j) { lsum[(pl - 1) * C + c + j] = s[j]; lsq[(pl - 1) * C + c + j] = ss[j]; }
       }
     }
   }
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
     for (int j = 0; j < cpg; ++j) {
       const int c = tid * cpg + j;
       float a = csum[c], q = csq[c];
-      for (int l = 1; l < PL; ++l) { a += lsum[l - 1][c]; q += lsq[l - 1][c]; }
+      for (int l = 1; l < PL; ++l) { a += lsum[(l - 1) * C + c]; q += lsq[(l - 1) * C + c]; }
       s += a; ss += q;
     }
     unsigned long long* dst = (unsigned long long*)p.acc + ((size_t)(b * 32 + tid) * GN_SLOTS + (chunk & (GN_SLOTS - 1))) * GN_WORDS;
@@ -101,7 +102,9 @@ __device__ __forceinline__ void gn_fold(const long long* acc, int b, int g, int 
   *rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
-// normalise (+SiLU); one channel quad per thread; grid (blocks per batch row, B)
+// normalise (+SiLU); U channel quads per thread (U = 4 on first-stage-sized maps so the per-block statistics fold is
+// amortised); grid (blocks per batch row, B)
+template <int U>
 __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p) {
   __shared__ float s_mean[32], s_rstd[32];
   const int C = p.c0 + p.c1;
@@ -114,30 +117,42 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p) {
     if ((tid & 7) == 0) { s_mean[tid >> 3] = m; s_rstd[tid >> 3] = r; }
   }
   __syncthreads();
-  const int64_t idx = (int64_t)blockIdx.x * 256 + tid;          // quad index inside this batch row
-  if (idx >= (int64_t)p.HW * nq) return;
-  const size_t pix = (size_t)b * p.HW + (size_t)(idx / nq);
-  const int c = (int)(idx % nq) * 4;
-  const f32x4 v = load_cat4(p.x0, p.x1, p.c0, p.c1, pix, c);
-  const f32x4 ga = *(const f32x4*)(p.gamma + c);
-  const f32x4 be = *(const f32x4*)(p.beta + c);
-  const int g0 = c / cpg, g1 = (c + 3) / cpg;          // a quad touches at most two groups (cpg >= 2)
-  const float m0 = s_mean[g0], r0 = s_rstd[g0], m1 = s_mean[g1], r1 = s_rstd[g1];
-  const int split = (g0 + 1) * cpg - c;                // first channel offset that belongs to g1
-  f32x4 y;
+  const int64_t total = (int64_t)p.HW * nq;
+  const int64_t base = (int64_t)blockIdx.x * (256 * U) + tid;   // quad index inside this batch row
+  f32x4 v[U]; size_t pix[U]; int ch[U];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const bool second = j >= split;
-    float t = (v[j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[j] + be[j];
-    if (p.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-    y[j] = t;
+  for (int u = 0; u < U; ++u) {
+    const int64_t idx = base + u * 256;
+    if (idx < total) {
+      pix[u] = (size_t)b * p.HW + (size_t)(idx / nq);
+      ch[u] = (int)(idx % nq) * 4;
+      v[u] = load_cat4(p.x0, p.x1, p.c0, p.c1, pix[u], ch[u]);
+    }
   }
-  const size_t o = pix * C + c;
-  if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-  if (p.out_lo) *(f16x4*)(p.out_lo + o) = lo_half(y);
-  if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
-  if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-  if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v);
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    if (base + u * 256 >= total) continue;
+    const int c = ch[u];
+    const f32x4 ga = *(const f32x4*)(p.gamma + c);
+    const f32x4 be = *(const f32x4*)(p.beta + c);
+    const int g0 = c / cpg, g1 = (c + 3) / cpg;          // a quad touches at most two groups (cpg >= 2)
+    const float m0 = s_mean[g0], r0 = s_rstd[g0], m1 = s_mean[g1], r1 = s_rstd[g1];
+    const int split = (g0 + 1) * cpg - c;                // first channel offset that belongs to g1
+    f32x4 y;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool second = j >= split;
+      float t = (v[u][j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[j] + be[j];
+      if (p.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+      y[j] = t;
+    }
+    const size_t o = pix[u] * C + c;
+    if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
+    if (p.out_lo) *(f16x4*)(p.out_lo + o) = lo_half(y);
+    if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
+    if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[u][0], (f16)v[u][1], (f16)v[u][2], (f16)v[u][3]};
+    if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v[u]);
+  }
 }
 
 // one wave per row
@@ -209,7 +224,10 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
   if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
     const int64_t quads = (int64_t)p.HW * (C / 4);
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p);
+    if (quads >= (int64_t)1 << 20)
+      hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((unsigned)((quads + 1023) / 1024), p.B), dim3(256), 0, stream, p);
+    else
+      hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p);
   }
   SDMI_HIP_OK(hipGetLastError());
   return 0;

@@ -409,21 +409,27 @@ struct Fwd : FwdBase {
     f16* xn_lo = precise_1x1 ? S<f16>((size_t)M * C) : nullptr;
     groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
     float* t = S<float>((size_t)M * C);
-    {
-      IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N);
-      p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
-      gemm(p);
-    }
     f16* ln = S<f16>((size_t)M * C);
     f16* q = S<f16>((size_t)M * C);
     f16* k = S<f16>((size_t)M * C);
     f16* vt = S<f16>((size_t)B * C * Np);
     f16* ao = S<f16>((size_t)M * C);
     f16* gg = S<f16>((size_t)M * 4 * C);
-    for (int d = 0; d < (int)L.tb.size(); ++d) {
+    // Every LayerNorm of the block reads the token stream `t` right after the GEMM that produced it, so it rides on
+    // that GEMM as a post-op (launch_igemm issues it after the GEMM / its split-K reduce): ln = LN(t).
+    auto with_ln = [&](IGemmParams& p, const float* gamma, const float* beta) {
+      p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = ln; p.ln_eps = 1e-5f;
+    };
+    {
+      IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N);
+      p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
+      with_ln(p, L.tb[0].ln[0], L.tb[0].ln[1]);                      // norm1 of the first block
+      gemm(p);
+    }
+    const int depth = (int)L.tb.size();
+    for (int d = 0; d < depth; ++d) {
       TBlock& T = L.tb[d];
       // x = attn1(norm1(x)) + x                                   attention.py:212
-      if (!dry && !rc) ok(launch_layernorm(t, T.ln[0], T.ln[1], ln, M, C, 1e-5f, s));
       {
         IGemmParams p = dense(ln, M, C, T.wqkv, 3 * C, N);
         p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_dst[1] = k; p.seg_dst[2] = vt;
@@ -439,10 +445,10 @@ struct Fwd : FwdBase {
       {
         IGemmParams p = dense(ao, M, C, T.wo1, C, N);
         p.bias = T.bo1; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
+        with_ln(p, T.ln[2], T.ln[3]);                                // norm2
         gemm(p);
       }
       // x = attn2(norm2(x), context) + x                           attention.py:213
-      if (!dry && !rc) ok(launch_layernorm(t, T.ln[2], T.ln[3], ln, M, C, 1e-5f, s));
       {
         IGemmParams p = dense(ln, M, C, T.wq2, C, N);
         p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_kind[0] = 0;
@@ -454,10 +460,10 @@ struct Fwd : FwdBase {
       {
         IGemmParams p = dense(ao, M, C, T.wo2, C, N);
         p.bias = T.bo2; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
+        with_ln(p, T.ln[4], T.ln[5]);                                // norm3
         gemm(p);
       }
       // x = ff(norm3(x)) + x                                       attention.py:214
-      if (!dry && !rc) ok(launch_layernorm(t, T.ln[4], T.ln[5], ln, M, C, 1e-5f, s));
       {
         IGemmParams p = dense(ln, M, C, T.wgg, 8 * C, N);
         p.mode = EPI_GEGLU; p.bias = T.bgg; p.out_f16 = gg; p.ldo = 4 * C; p.splitk = 1;
@@ -465,11 +471,17 @@ struct Fwd : FwdBase {
       }
       {
         IGemmParams p = dense(gg, M, 4 * C, T.wff2, C, N);
-        p.bias = T.bff2; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
+        p.bias = T.bff2; p.residual = t; p.ldr = C; p.ldo = C;
+        if (d + 1 < depth) {
+          p.out_f32 = t;
+          with_ln(p, L.tb[d + 1].ln[0], L.tb[d + 1].ln[1]);          // norm1 of the next block
+        } else {
+          // last block: only proj_out reads the result -- emit its split-fp16 operand (hi | lo) directly
+          p.out_f16 = ln; p.out_lo = xn_lo;
+        }
         gemm(p);
       }
     }
-    if (!dry && !rc) ok(launch_cast_f16(t, ln, xn_lo, (int64_t)M * C, s));
     Act out; out.p = P<float>((size_t)M * C); out.C = C; out.H = H; out.W = W;
     {
       IGemmParams p = dense1x1(ln, xn_lo, M, C, L.w16[1], C, N);

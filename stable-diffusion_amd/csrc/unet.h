@@ -155,8 +155,10 @@ class UNet {
   // 1x1 convs on the residual stream (skip_connection, proj_in, proj_out) run as 3-pass split-fp16 GEMMs
   // (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): ~22-bit operands for 5 % of the FLOPs (DESIGN.md "precision")
   bool precise_1x1_ = true;
-  // ResBlock convs at >= 32x32 run as fused GroupNorm+SiLU+conv3x3 with halo-staged input tiles (conv3gn.hip)
-  bool fuse_gn_conv_ = true;
+  // opt-in (SDMI_FUSE_GN_CONV=1): ResBlock convs at >= 32x32 as fused GroupNorm+SiLU+conv3x3 with halo-staged input
+  // tiles (conv3gn.hip).  Same-box A/B: the fused path is 0.7 ms / UNet call SLOWER than GroupNorm + igemm
+  // (8.89 vs 8.18 ms, profiles/ab_conv3gn_reduce_ln_r01.txt), so it is off by default.
+  bool fuse_gn_conv_ = false;
 
  private:
   friend struct Fwd;
