@@ -139,7 +139,7 @@ typedef struct sdmi_igemm_desc {
   int32_t splitk;                       /* 1 none, 0 auto, >1 forced (plain mode; needs splitk_ws) */
   float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs [splitk][M][N] */
   int32_t tile;                         /* -1 auto; 0 128x128, 1 128x64, 2 64x64, 3 256x128 (8 waves) -- double buffered;
-                                           4 128x64, 5 64x64 with a 3-stage LDS-DMA pipeline */
+                                           4 128x64, 5 64x64, 6 256x128, 7 128x128 with a 3-stage LDS-DMA pipeline */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
   int32_t asym_pad;                     /* 3x3 only: 0 = zero pad 1 on every side; 1 = pad right/bottom only, i.e.
                                            F.pad(x,(0,1,0,1)) + conv(padding=0) of the VAE Downsample (model.py:72-76) */

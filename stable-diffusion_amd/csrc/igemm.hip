@@ -551,16 +551,22 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   static const int env_tile = env_int("SDMI_IGEMM_TILE", -1);
   const bool dma = (tune.dma >= 0 ? tune.dma : env_dma) != 0;
   int tile = tune.tile >= 0 ? tune.tile : env_tile;
-  if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3)) tile = 0;   // GEGLU pairs 32-col tiles inside a wave
+  static const int env_geglu = env_int("SDMI_TILE_GEGLU", 0);
+  if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3 || tile == 6 || tile == 7)) tile = env_geglu;   // GEGLU pairs 32-col tiles inside a wave
   // Tile / split-K choice, from the per-shape sweep of tools/bench_kernels.py on MI355X (profiles/kbench_r01.txt):
   // every shape of this UNet is bound by L2->LDS bytes in flight, so the many-block 64x64 tile wins except for
   // the few >= 25 GFLOP convs, where the 256x128 tile (fewest bytes per FLOP) is ~10 % faster.
   const double gflop = 2.0 * p.M * (double)p.N * p.K * 1e-9;
   if (tile < 0) {
-    if (p.mode == EPI_HEADS) tile = 2;
-    else tile = (gflop >= 25.0) ? 3 : 2;
+    static const int env_small = env_int("SDMI_TILE_SMALL", 5);       // tuning knobs for same-box A/B runs (tools/gpu_ab.sh)
+    static const int env_t5kt = env_int("SDMI_T5_MIN_KT", 0);         // 3-stage tile only when K has >= this many k-tiles
+    static const int env_heads = env_int("SDMI_TILE_HEADS", 2);
+    static const int env_t3 = env_int("SDMI_T3_GFLOP", 25);
+    static const int env_big = env_int("SDMI_TILE_BIG", 3);
+    if (p.mode == EPI_HEADS) tile = env_heads;
+    else tile = (gflop >= (double)env_t3) ? env_big : ((env_small == 5 && p.K / BK < env_t5kt) ? 2 : env_small);
   }
-  const int BMs[6] = {128, 128, 64, 256, 128, 64}, BNs[6] = {128, 64, 64, 128, 64, 64};
+  const int BMs[8] = {128, 128, 64, 256, 128, 64, 256, 128}, BNs[8] = {128, 64, 64, 128, 64, 64, 128, 128};
   int splitk = p.splitk;
   const int nkt = p.K / BK;
   static const int env_split = env_int("SDMI_SPLITK", -1);     // 1 disables split-K everywhere
@@ -572,7 +578,8 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     if (can_split) {
       const long blocks = (long)cdiv(p.M, BMs[tile]) * cdiv(p.N, BNs[tile]);
       static const int env_want = env_int("SDMI_SPLIT_WANT", 512);
-      const long want = (tile == 3) ? 160 : env_want;
+      static const int env_want3 = env_int("SDMI_SPLIT_WANT3", 160);
+      const long want = (tile == 3 || tile == 6) ? env_want3 : env_want;
       while (blocks * splitk < want && nkt / (splitk * 2) >= 8 && splitk < 16 &&
              (int64_t)(splitk * 2) * p.M * p.N <= p.splitk_ws_floats)
         splitk *= 2;
@@ -589,6 +596,8 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     case 3: return launch_cfg<256, 128, 4, 2, 2>(p, dma, splitk, stream);
     case 4: return launch_cfg<128, 64, 2, 2, 3>(p, dma, splitk, stream);
     case 5: return launch_cfg<64, 64, 2, 2, 3>(p, dma, splitk, stream);
+    case 6: return launch_cfg<256, 128, 4, 2, 3>(p, dma, splitk, stream);
+    case 7: return launch_cfg<128, 128, 2, 2, 3>(p, dma, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }

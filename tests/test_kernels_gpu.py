@@ -51,7 +51,7 @@ def _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up):
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7])
 @pytest.mark.parametrize('dma', [0, 1])
 def test_igemm_conv(case, tile, dma):
     name, B, Hin, Win, c0, c1, N, ksize, stride, up = case
@@ -167,7 +167,7 @@ def test_igemm_geglu():
     val, gate = y.chunk(2, dim=-1)
     ref = val * F.gelu(gate)
     wp, bp = K.pack_geglu(w.float().to(DEV), b.to(DEV))
-    for tile in (0, 3):
+    for tile in (0, 3, 6, 7):
         out = torch.full((M, N // 2), float('nan'), device=DEV, dtype=torch.float16)
         K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1, tile=tile)
         torch.cuda.synchronize()
