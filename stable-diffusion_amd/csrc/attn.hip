@@ -219,12 +219,15 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
 
 template <int D>
 int launch_d(const AttnParams& p, hipStream_t stream) {
-  // Few, latency-bound workgroups (short sequences at the 16x16 / 8x8 levels): use as many waves as there are
-  // 32-query slices so the K/V tile loads are spread over more threads; long sequences: 8 waves share each tile.
+  // Long sequences (> 1024 queries): 8 waves share each K/V tile.  Short ones (the 32x32 / 16x16 / 8x8 levels) are
+  // latency bound with few workgroups: at most 4 waves per workgroup so there are more of them.
   int nw = p.nw;
   if (nw <= 0) {
     const int slices = cdiv(p.nq, 32);
-    nw = slices >= 8 ? 8 : (slices >= 4 ? 4 : 2);
+    // (same-box A/B, profiles/ab_*_r01.txt: 4 waves beat 8 up to 1024 queries -- more, smaller workgroups)
+    nw = (slices >= 8 && p.nq > 1024) ? 8 : (slices >= 4 ? 4 : 2);
+    static const int env_small = getenv("SDMI_ATTN_NW_LE1K") ? atoi(getenv("SDMI_ATTN_NW_LE1K")) : 0;   // A/B knob
+    if (env_small > 0 && p.nq <= 1024) nw = env_small;
   }
   dim3 grid(cdiv(p.nq, 32 * nw), p.BH);
   static const std::string pname = std::string("attn_d") + std::to_string(D);

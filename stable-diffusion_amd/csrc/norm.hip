@@ -224,7 +224,8 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
   if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
     const int64_t quads = (int64_t)p.HW * (C / 4);
-    if (quads >= (int64_t)1 << 20)
+    static const int64_t u4_from = getenv("SDMI_GN_APPLY_U4_QUADS") ? atoll(getenv("SDMI_GN_APPLY_U4_QUADS")) : ((int64_t)1 << 20);   // A/B knob
+    if (quads >= u4_from)
       hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((unsigned)((quads + 1023) / 1024), p.B), dim3(256), 0, stream, p);
     else
       hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p);
