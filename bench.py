@@ -115,7 +115,7 @@ def unet_latency_ms(unet, device, H=64, W=64, iters=10):
 
 def offline_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic_r01.json);
-    PMC counters cannot be collected inside this process, so `roofline.traffic` itself stays null."""
+    PMC counters cannot be collected inside this process, so `roofline.traffic` is read from that committed pass."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r01.json')))
         k = d['kernels'].get(kernel_class)
@@ -261,7 +261,11 @@ def main():
                     'bound': 'mfma', 'kernel': dom['name'], 'launches_per_unet_call': dom['launches'],
                     'avg_launch_ms': dom['ms'] / dom['launches'],
                     'achieved': ach, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': (ach / MFMA_PEAK_TFLOPS) if ach else None, 'traffic': None, 'traffic_offline': offline_traffic(dom['name']),
+                    'frac': (ach / MFMA_PEAK_TFLOPS) if ach else None,
+                    # HBM bytes per launch of this kernel class from the committed rocprofv3 PMC passes over the same
+                    # UNet call (separate FETCH_SIZE / WRITE_SIZE passes cannot run inside this process); null if absent
+                    'traffic': (lambda t: t['gbytes_per_launch'] * 1e9 if t else None)(offline_traffic(dom['name'])),
+                    'traffic_unit': 'bytes/launch', 'traffic_offline': offline_traffic(dom['name']),
                     'algorithmic_gbytes_per_launch': dom['bytes'] / dom['launches'] / 1e9,
                     'per_class': [{'name': r['name'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
                                    'tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if r['flops'] else None,

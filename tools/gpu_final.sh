@@ -2,8 +2,10 @@
 # Round-end verification on one box: the driver's own sequence (pytest -m gpu -x, smoke, default bench) + rocprofv3 summaries.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp PYTHONUNBUFFERED=1
 O=$PWD/gpurun_out; mkdir -p $O/benchprof $O/pmc_unet
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
 timeout 1200 python -m pytest tests -x -q -m gpu -p no:cacheprovider > $O/pytest_gpu.log 2>&1; echo "pytest exit $? : $(tail -1 $O/pytest_gpu.log)"
 timeout 600 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1; echo "smoke exit $?"; grep smoke: $O/smoke.log
+fi
 timeout 900 python bench.py > $O/bench_full.log 2>&1; echo "bench exit $?"; tail -1 $O/bench_full.log | cut -c1-300
 timeout 900 rocprofv3 --kernel-trace --stats -d $O/benchprof -o bench -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline > $O/benchprof.log 2>&1; echo "prof exit $?"
 python - <<'PY'
@@ -42,3 +44,26 @@ with open('gpurun_out/pmc_unet/traffic_by_kernel.txt','w') as out:
         out.write(f'{name:70s} {n:8d} {f/n/1024:16.2f} {2*f/n/1024:10.2f} {w/n/1024:16.2f}\n')
 print(open('gpurun_out/pmc_unet/traffic_by_kernel.txt').read()[:2500])
 PY
+timeout 600 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES -d $O/pmc_unet/SQ -o pmc -- python tools/prof_shapes.py > $O/pmc_unet/SQ.log 2>&1; echo "SQ exit $?"
+python - <<'PY'
+import sqlite3, glob, collections
+res=collections.defaultdict(dict)
+for f in glob.glob('gpurun_out/pmc_unet/SQ/*_results.db'):
+    con=sqlite3.connect(f)
+    for k,c,v,n in con.execute("select kernel_name, counter_name, sum(value), count(distinct dispatch_id) from counters_collection group by kernel_name, counter_name"):
+        res[k][c]=(v,n)
+with open('gpurun_out/pmc_unet/sq_by_kernel.txt','w') as out:
+    out.write('rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES over tools/prof_shapes.py\n')
+    out.write('(2 UNet calls, CFG batch 2, 64x64).  WAIT_ANY = parked on s_waitcnt / barrier, WAIT_INST_ANY = issue stalls, ACTIVE = issuing; fractions of SQ_WAVE_CYCLES;\n')
+    out.write('mfma_Mcyc = SQ_VALU_MFMA_BUSY_CYCLES per launch / 1e6 (summed over the SIMDs; utilisation = that / (1024 SIMDs x duration x clock))\n')
+    out.write(f'{"kernel":64s} {"launches":>8s} {"wait_any":>9s} {"wait_inst":>9s} {"active":>8s} {"mfma_Mcyc":>9s}\n')
+    for k,d in sorted(res.items(), key=lambda kv:-kv[1].get('SQ_WAVE_CYCLES',(0,1))[0]):
+        if 'sdmi' not in k: continue
+        wc,n=d.get('SQ_WAVE_CYCLES',(1,1)); wc=max(wc,1)
+        g=lambda c: d.get(c,(0,1))[0]
+        name=k.split('sdmi::(anonymous namespace)::')[-1][:62]
+        out.write(f'{name:64s} {n:8d} {g("SQ_WAIT_ANY")/wc:9.3f} {g("SQ_WAIT_INST_ANY")/wc:9.3f} {g("SQ_ACTIVE_INST_ANY")/wc:8.3f} {g("SQ_VALU_MFMA_BUSY_CYCLES")/n/1e6:9.3f}\n')
+print(open('gpurun_out/pmc_unet/sq_by_kernel.txt').read()[:2500])
+PY
+# keep only the text summaries (the rocprofv3 databases exceed the 64 MiB gpurun_out budget)
+find $O/benchprof $O/pmc_unet -type f ! -name '*.txt' ! -name '*.log' -delete; find $O -type d -empty -delete; du -sh $O
