@@ -108,6 +108,29 @@ def test_context_cache_and_repeatability():
     assert torch.equal(e1, e6)
 
 
+@pytest.mark.parametrize('cfg_name,B,h,w', [('tiny', 6, 16, 16), ('sdv1', 6, 16, 16), ('sdv1', 8, 8, 8), ('sdv1', 3, 32, 32)])
+def test_batch_rows_are_independent(cfg_name, B, h, w):
+    """txt2img's default n_samples = 3 gives a CFG batch of 6 (scripts/txt2img.py:110-114): the reference has no
+    cross-sample op (GroupNorm is per sample, attention per sample), so a batch of B must equal B single-row calls
+    with per-row timesteps / contexts.  Tile and split-K choices depend on M, so the two differ by fp16 operand-rounding
+    noise: both are within TOL of the fp32 truth, hence within 2 * TOL of each other (measured value is printed)."""
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, 0)
+    x, t, ctx = make_inputs(cfg, B, h, w, seed=11)
+    xc, tc, cc = x.cuda(), t.cuda(), ctx.cuda()
+    whole = m(xc, tc, context=cc)
+    assert whole.shape == (B, cfg.out_channels, h, w) and torch.isfinite(whole).all()
+    worst = 0.0
+    for i in range(B):
+        one = m(xc[i:i + 1].contiguous(), tc[i:i + 1].contiguous(), context=cc[i:i + 1].contiguous())
+        worst = max(worst, (one - whole[i:i + 1]).abs().max().item())
+    print(f'[unet batch {cfg_name} B={B} {h}x{w}] batched vs row-by-row max-abs {worst:.3e}', flush=True)
+    assert worst <= 2 * TOL
+    with pytest.raises(RuntimeError):
+        m(torch.zeros(9, cfg.in_channels, 8, 8, device='cuda'), torch.zeros(9, dtype=torch.long, device='cuda'),
+          context=torch.zeros(9, 77, cfg.context_dim, device='cuda'))        # > 8 rows per call is refused, not truncated
+
+
 def test_refuses_cpu_and_bad_config():
     from stable_diffusion_amd import UNetModelHIP
     m, sd = _model('tiny', 0)
