@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 2
+#define SDMI_ABI_VERSION 3
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -123,6 +123,34 @@ int64_t sdmi_vae_encode_workspace_bytes(sdmi_vae* h, int B, int H, int W);
 int sdmi_vae_encode(sdmi_vae* h, const float* img, float* moments, int B, int H, int W, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+
+/* ---- text encoder (FrozenCLIPEmbedder): SURVEY.md 8 f-2 ----------------------------------------------------------
+ * Replaces `self.transformer(input_ids=tokens).last_hidden_state` of FrozenCLIPEmbedder.forward
+ * (ldm/modules/encoders/modules.py:155-160); `self.transformer` is transformers' CLIPTextModel (transformers==4.19.2,
+ * environment.yaml:25; models/clip/modeling_clip.py).  The tokenizer stays on the host. */
+typedef struct sdmi_clip sdmi_clip;
+/* CLIPTextConfig fields (openai/clip-vit-large-patch14: 49408, 768, 3072, 12, 12, 77); hidden_act = quick_gelu */
+typedef struct sdmi_clip_cfg {
+  int32_t vocab_size;
+  int32_t hidden_size;
+  int32_t intermediate_size;
+  int32_t num_layers;
+  int32_t num_heads;
+  int32_t max_positions;
+} sdmi_clip_cfg;
+int sdmi_clip_create(const sdmi_clip_cfg* cfg, sdmi_clip** out);
+int sdmi_clip_destroy(sdmi_clip* h);
+/* state_dict keys of CLIPTextModel as transformers 4.19.2 names them (`text_model.embeddings...`, `text_model.encoder
+ * .layers.N...`, `text_model.final_layer_norm...`), i.e. the checkpoint's `cond_stage_model.transformer.` sub-tree */
+int sdmi_clip_num_weights(const sdmi_clip* h);
+int sdmi_clip_weight_info(const sdmi_clip* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim);
+int sdmi_clip_set_weight(sdmi_clip* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream);
+int sdmi_clip_finalize(sdmi_clip* h);
+int64_t sdmi_clip_workspace_bytes(sdmi_clip* h, int B, int L);
+/* ids: int64 [B, L] token ids (device); out: fp32 [B, L, hidden_size] = last_hidden_state */
+int sdmi_clip_forward(sdmi_clip* h, const int64_t* ids, float* out, int B, int L, void* workspace, int64_t workspace_bytes,
+                      void* stream);
+
 /* ---- kernel-level entry points (parity tests and micro-benchmarks; same kernels the UNet uses) ---------- */
 typedef struct sdmi_igemm_desc {
   const void* a0; const void* a1; const void* a2;   /* fp16 NHWC sources, channel concat [a0|a1|a2] (a1, a2 optional) */
@@ -148,6 +176,9 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
 int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
                      int nkv_pad, int d, float scale, void* stream);
+/* same with a causal mask (query i attends to keys <= i; nq == nkv): CLIPTextModel's self-attention */
+int sdmi_k_attention_causal(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int n, int n_pad,
+                            int d, float scale, void* stream);
 /* GroupNorm(32) over cat(x0,x1) fp32 NHWC; any of the outputs may be NULL.  out_lo / raw_lo = fp16(v - fp16(v)):
  * the low halves of split-fp16 operands (3-pass 1x1 convs) */
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,

@@ -7,6 +7,7 @@ this package is the host-side mirror of the reference's interfaces for that path
     PLMSSamplerHIP    <- ldm.models.diffusion.plms.PLMSSampler
     DDIMSamplerHIP    <- ldm.models.diffusion.ddim.DDIMSampler
     AutoencoderKLHIP  <- ldm.models.autoencoder.AutoencoderKL (decode / encode)
+    FrozenCLIPEmbedderHIP <- ldm.modules.encoders.modules.FrozenCLIPEmbedder
 
 Importable as `stable_diffusion_amd` (see stable_diffusion_amd.py at the repo root).
 """
@@ -14,6 +15,7 @@ from . import _lib  # noqa: F401
 from .unet import UNetModelHIP  # noqa: F401
 from .samplers import PLMSSamplerHIP, DDIMSamplerHIP  # noqa: F401
 from .vae import AutoencoderKLHIP  # noqa: F401
+from .clip import FrozenCLIPEmbedderHIP  # noqa: F401
 from .ldm_shim import LatentDiffusionHIP, DiffusionWrapperHIP  # noqa: F401
 
-__all__ = ['UNetModelHIP', 'AutoencoderKLHIP', 'PLMSSamplerHIP', 'DDIMSamplerHIP', 'LatentDiffusionHIP', 'DiffusionWrapperHIP']
+__all__ = ['UNetModelHIP', 'AutoencoderKLHIP', 'FrozenCLIPEmbedderHIP', 'PLMSSamplerHIP', 'DDIMSamplerHIP', 'LatentDiffusionHIP', 'DiffusionWrapperHIP']

@@ -22,6 +22,11 @@ class VaeCfg(C.Structure):
                 ('embed_dim', C.c_int32)]
 
 
+class ClipCfg(C.Structure):
+    _fields_ = [('vocab_size', C.c_int32), ('hidden_size', C.c_int32), ('intermediate_size', C.c_int32),
+                ('num_layers', C.c_int32), ('num_heads', C.c_int32), ('max_positions', C.c_int32)]
+
+
 class IGemmDesc(C.Structure):
     _fields_ = [('a0', c_ptr), ('a1', c_ptr), ('a2', c_ptr),
                 ('c0', C.c_int32), ('c1', C.c_int32), ('c2', C.c_int32),
@@ -63,7 +68,17 @@ _SIGS = {
     'sdmi_vae_decode': (C.c_int, [c_ptr, c_ptr, C.c_float, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
     'sdmi_vae_encode_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int, C.c_int]),
     'sdmi_vae_encode': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_clip_create': (C.c_int, [C.POINTER(ClipCfg), C.POINTER(c_ptr)]),
+    'sdmi_clip_destroy': (C.c_int, [c_ptr]),
+    'sdmi_clip_num_weights': (C.c_int, [c_ptr]),
+    'sdmi_clip_weight_info': (C.c_int, [c_ptr, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
+    'sdmi_clip_set_weight': (C.c_int, [c_ptr, C.c_char_p, c_ptr, C.POINTER(C.c_int64), C.c_int, c_ptr]),
+    'sdmi_clip_finalize': (C.c_int, [c_ptr]),
+    'sdmi_clip_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int]),
+    'sdmi_clip_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_igemm': (C.c_int, [C.POINTER(IGemmDesc), c_ptr]),
+    'sdmi_k_attention_causal': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                          c_ptr]),
     'sdmi_k_pointwise_nchw': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_ptr]),
     'sdmi_k_softmax_rows': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     'sdmi_k_attention': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -109,7 +124,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 2:
+        if lib.sdmi_abi_version() != 3:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -6,6 +6,7 @@
 #include "prof.h"
 #include "unet.h"
 #include "vae.h"
+#include "clip.h"
 
 namespace sdmi {
 static thread_local std::string g_err;
@@ -15,6 +16,7 @@ int fail(const std::string& msg) { g_err = msg; return -1; }
 
 struct sdmi_unet { sdmi::UNet impl; };
 struct sdmi_vae { sdmi::Vae impl; };
+struct sdmi_clip { sdmi::ClipText impl; };
 
 using namespace sdmi;
 
@@ -149,6 +151,52 @@ int sdmi_k_pointwise_nchw(const float* x, const float* w, const float* bias, flo
 }
 int sdmi_k_softmax_rows(const float* S, void* P_f16, int rows, int cols, float scale, void* stream) {
   return launch_softmax_rows(S, (f16*)P_f16, rows, cols, cols, cols, scale, (hipStream_t)stream);
+}
+
+
+// ---- text encoder -------------------------------------------------------------------------------------
+int sdmi_clip_create(const sdmi_clip_cfg* cfg, sdmi_clip** out) {
+  SDMI_CHECK(cfg && out, "null argument");
+  sdmi_clip* h = new (std::nothrow) sdmi_clip();
+  SDMI_CHECK(h != nullptr, "out of host memory");
+  if (h->impl.build(*cfg)) { delete h; return -1; }
+  *out = h;
+  return 0;
+}
+int sdmi_clip_destroy(sdmi_clip* h) { delete h; return 0; }
+int sdmi_clip_num_weights(const sdmi_clip* h) { return h ? (int)h->impl.slots().size() : fail("null handle"); }
+int sdmi_clip_weight_info(const sdmi_clip* h, int idx, char* key_buf, int key_buf_len, int64_t* shape4, int* ndim) {
+  SDMI_CHECK(h && key_buf && shape4 && ndim, "null argument");
+  SDMI_CHECK(idx >= 0 && idx < (int)h->impl.slots().size(), "weight index out of range");
+  const CWeightSlot& s = h->impl.slots()[idx];
+  SDMI_CHECK((int)s.key.size() + 1 <= key_buf_len, "key buffer too small");
+  memcpy(key_buf, s.key.c_str(), s.key.size() + 1);
+  *ndim = (int)s.shape.size();
+  for (int i = 0; i < 4; ++i) shape4[i] = i < *ndim ? s.shape[i] : 1;
+  return 0;
+}
+int sdmi_clip_set_weight(sdmi_clip* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream) {
+  SDMI_CHECK(h && key && ptr && shape, "null argument");
+  return h->impl.set_weight(key, ptr, shape, ndim, (hipStream_t)stream);
+}
+int sdmi_clip_finalize(sdmi_clip* h) { SDMI_CHECK(h, "null handle"); return h->impl.finalize(); }
+int64_t sdmi_clip_workspace_bytes(sdmi_clip* h, int B, int L) {
+  if (!h) { fail("null handle"); return 0; }
+  int64_t need = 0;
+  if (h->impl.forward(nullptr, nullptr, B, L, nullptr, 0, nullptr, true, &need)) return 0;
+  return need;
+}
+int sdmi_clip_forward(sdmi_clip* h, const int64_t* ids, float* out, int B, int L, void* workspace, int64_t workspace_bytes,
+                      void* stream) {
+  SDMI_CHECK(h && ids && out, "null argument");
+  return h->impl.forward(ids, out, B, L, workspace, workspace_bytes, (hipStream_t)stream, false, nullptr);
+}
+int sdmi_k_attention_causal(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int n, int n_pad,
+                            int d, float scale, void* stream) {
+  AttnParams a;
+  a.q = (const f16*)q; a.k = (const f16*)k; a.vt = (const f16*)vt; a.out = (f16*)out;
+  a.BH = BH; a.heads = heads; a.nq = n; a.nkv = n; a.nkv_pad = n_pad; a.d = d; a.scale = scale; a.causal = 1;
+  return launch_attention(a, (hipStream_t)stream);
 }
 
 // ---- kernel-level entry points ------------------------------------------------------------------------

@@ -140,13 +140,14 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
     }
     // ---- mask keys beyond nkv (last tile only) ----
     const int kv0 = t * KVT;
-    if (kv0 + KVT > p.nkv) {
+    if (kv0 + KVT > p.nkv || p.causal) {
+      const int qlim = p.causal ? (q0 + l31) : 0x7fffffff;       // causal: this lane's query sees keys <= its own index
 #pragma unroll
       for (int kvb = 0; kvb < KVT / 32; ++kvb)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int kv = kv0 + kvb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-          if (kv >= p.nkv) s[kvb][r] = -1e30f;
+          if (kv >= p.nkv || kv > qlim) s[kvb][r] = -1e30f;
         }
     }
     // ---- online softmax (per query = per lane column; halves lg = 0/1 hold disjoint keys) ----
@@ -244,6 +245,7 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
 int launch_attention(const AttnParams& p, hipStream_t stream) {
   SDMI_CHECK(p.BH > 0 && p.nq > 0 && p.nkv > 0 && p.heads > 0 && p.BH % p.heads == 0, "bad attention shape");
   SDMI_CHECK(p.nkv_pad % 8 == 0 && p.nkv_pad >= p.nkv, "nkv_pad must be a multiple of 8 and >= nkv");
+  SDMI_CHECK(!p.causal || p.nq == p.nkv, "causal attention needs nq == nkv");
   switch (p.d) {
     case 32: return launch_d<32>(p, stream);
     case 40: return launch_d<40>(p, stream);

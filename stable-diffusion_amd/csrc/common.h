@@ -126,6 +126,7 @@ struct AttnParams {
   int BH = 0, heads = 0, nq = 0, nkv = 0, nkv_pad = 0, d = 0;
   float scale = 1.f;
   int nw = 0;                // waves per workgroup (0 = auto): each wave owns 32 queries
+  int causal = 0;            // 1: key j attends only to queries i >= j (CLIP text model); needs nq == nkv
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
 
@@ -154,7 +155,7 @@ static inline int64_t gn_acc_words(int B) { return (int64_t)B * 32 * GN_SLOTS * 
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,
-                     hipStream_t stream);
+                     hipStream_t stream, float* out_f32 = nullptr);     // out / out_f32: either or both
 int launch_cast_f16(const float* x, f16* out, f16* out_lo, int64_t n, hipStream_t stream);
 
 // fp32 "small" path
@@ -165,6 +166,11 @@ int launch_conv_in(const float* x_nchw, const float* w, const float* bias, float
                    int W, int Cout, hipStream_t s);
 int launch_conv_out(const float* h_nhwc, const float* w_khwc, const float* bias, float* out_nchw, int B, int H, int W,
                     int Cin, int Cout, hipStream_t s);
+
+// text-encoder helpers: out[m][:] = tok_emb[ids[m]][:] + pos_emb[m % L][:] (fp32); out16 = fp16(x * sigmoid(1.702 x))
+int launch_embed_tokens(const int64_t* ids, const float* tok_emb, const float* pos_emb, float* out, int M, int L, int C,
+                        int vocab, hipStream_t s);
+int launch_quick_gelu(const float* x, f16* out, int64_t n, hipStream_t s);
 
 // first-stage (VAE) helpers
 int launch_pointwise_nchw(const float* x_nchw, const float* w, const float* bias, float* out_nchw, int B, int Cin, int Cout,

@@ -417,6 +417,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
       const int dd = c - head * p.dh;
       f16* dst = p.seg_dst[seg];
       const int kind = p.seg_kind[seg];
+      if (p.bias) {                        // q/k/v projections with a bias (CLIP text model); the UNet's have none
+        const float bv = p.bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+      }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll

@@ -158,7 +158,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p) {
 // one wave per row
 template <int MAXQ>
 __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const float* gamma, const float* beta, f16* out,
-                                                        int M, int C, float eps) {
+                                                        int M, int C, float eps, float* out32) {
   const int lane = threadIdx.x & 63;
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
@@ -186,17 +186,17 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const fl
 #pragma unroll
   for (int o = 32; o >= 1; o >>= 1) ss += __shfl_xor(ss, o);
   const float rstd = 1.0f / sqrtf(ss / (float)C + eps);
-  f16* orow = out + (size_t)row * C;
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) {
     const int c = (i * 64 + lane) * 4;
     if (c < C) {
       const f32x4 ga = *(const f32x4*)(gamma + c);
       const f32x4 be = *(const f32x4*)(beta + c);
-      f16x4 y;
+      f32x4 y32;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) y[j] = (f16)((v[i][j] - mean) * rstd * ga[j] + be[j]);
-      *(f16x4*)(orow + c) = y;
+      for (int j = 0; j < 4; ++j) y32[j] = (v[i][j] - mean) * rstd * ga[j] + be[j];
+      if (out) *(f16x4*)(out + (size_t)row * C + c) = f16x4{(f16)y32[0], (f16)y32[1], (f16)y32[2], (f16)y32[3]};
+      if (out32) *(f32x4*)(out32 + (size_t)row * C + c) = y32;
     }
   }
 }
@@ -235,12 +235,12 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
 }
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,
-                     hipStream_t stream) {
+                     hipStream_t stream, float* out_f32) {
   SDMI_CHECK(C % 4 == 0 && C <= 2560, "LayerNorm: C must be a multiple of 4 and <= 2560");
   dim3 grid(cdiv(M, 4)), block(256);
   ProfScope ps("layernorm", 0.0, (double)M * C * 6.0, stream);
-  if (C <= 1280) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps);
-  else hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps);
+  if (C <= 1280) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  else hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

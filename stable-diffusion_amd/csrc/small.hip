@@ -225,6 +225,30 @@ static int get_freqs(int half, const float** out) {
 }
 
 
+// ---- text-encoder helpers ---------------------------------------------------------------------------------------------
+// CLIPTextEmbeddings (transformers models/clip/modeling_clip.py): token_embedding(ids) + position_embedding(arange(L))
+__global__ void __launch_bounds__(256) embed_tokens_kernel(const int64_t* ids, const float* tok, const float* pos, float* out,
+                                                           int M, int L, int C, int vocab) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int nq = C / 4;
+  if (idx >= (int64_t)M * nq) return;
+  const int m = (int)(idx / nq), c = (int)(idx - (int64_t)m * nq) * 4;
+  int64_t id = ids[m];
+  id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);              // the host shim validates the range; never read out of bounds
+  *(f32x4*)(out + (size_t)m * C + c) = *(const f32x4*)(tok + (size_t)id * C + c) + *(const f32x4*)(pos + (size_t)(m % L) * C + c);
+}
+
+// quick_gelu (CLIP's hidden_act): x * sigmoid(1.702 x), fp32 in -> fp16 out
+__global__ void __launch_bounds__(256) quick_gelu_kernel(const float* x, f16* out, int64_t n4) {
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = *(const f32x4*)(x + i * 4);
+  f16x4 y;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) y[j] = (f16)(v[j] / (1.0f + __expf(-1.702f * v[j])));
+  *(f16x4*)(out + i * 4) = y;
+}
+
 // ---- first-stage (VAE) helpers ---------------------------------------------------------------------------------------
 // 1x1 conv on a few channels, NCHW fp32 -> NCHW fp32, input optionally pre-scaled:
 // post_quant_conv / quant_conv (ldm/models/autoencoder.py:302-303) and the 1/scale_factor of decode_first_stage
@@ -321,6 +345,23 @@ int launch_conv_out(const float* h, const float* w, const float* bias, float* ou
   return 0;
 }
 
+
+int launch_embed_tokens(const int64_t* ids, const float* tok_emb, const float* pos_emb, float* out, int M, int L, int C,
+                        int vocab, hipStream_t s) {
+  SDMI_CHECK(C % 4 == 0 && M >= 1 && L >= 1 && vocab >= 1, "embed_tokens: C % 4");
+  const int64_t total = (int64_t)M * (C / 4);
+  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ids, tok_emb, pos_emb, out, M,
+                     L, C, vocab);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+int launch_quick_gelu(const float* x, f16* out, int64_t n, hipStream_t s) {
+  SDMI_CHECK(n % 4 == 0, "quick_gelu: n % 4");
+  hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n / 4);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int launch_pointwise_nchw(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int Cout, int HW,
                           float in_scale, hipStream_t s) {

@@ -45,10 +45,13 @@ struct FwdBase {
   }
   long long* last_gn_acc() const { return gn_acc + (size_t)(gn_calls - 1) * gn_acc_words(B); }
   // allocate + zero the accumulator regions and the split-K slabs (call once per pass, before any layer)
-  int begin_pass(int64_t splitk_floats) {
+  int begin_pass(int64_t splitk_floats, bool with_gn = true) {
     gn_calls = 0;
-    gn_acc = P<long long>((size_t)GN_MAX_CALLS * gn_acc_words(B));
-    if (!dry) SDMI_HIP_OK(hipMemsetAsync(gn_acc, 0, (size_t)GN_MAX_CALLS * gn_acc_words(B) * sizeof(long long), s));
+    gn_acc = nullptr;
+    if (with_gn) {
+      gn_acc = P<long long>((size_t)GN_MAX_CALLS * gn_acc_words(B));
+      if (!dry) SDMI_HIP_OK(hipMemsetAsync(gn_acc, 0, (size_t)GN_MAX_CALLS * gn_acc_words(B) * sizeof(long long), s));
+    }
     splitk_ws_floats = splitk_floats;
     splitk_ws = P<float>((size_t)splitk_floats);
     return 0;

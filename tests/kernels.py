@@ -84,6 +84,15 @@ def attention(q, k, vt, heads, nkv, scale):
     return out
 
 
+def attention_causal(q, k, vt, heads, scale):
+    """q, k [BH,n,d], vt [BH,d,n_pad] fp16 -> [B, n, heads*d] fp16, query i sees keys <= i"""
+    BH, n, d = q.shape
+    out = torch.empty((BH // heads, n, heads * d), dtype=torch.float16, device=q.device)
+    _lib.check(_lib.load().sdmi_k_attention_causal(q.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), BH, heads, n,
+                                                   vt.shape[2], d, float(scale), _s()))
+    return out
+
+
 def groupnorm(x0, x1, gamma, beta, eps, silu, want=('f16',)):
     """x0/x1: fp32 [B, HW, C] -> dict of outputs"""
     B, HW, c0 = x0.shape

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 2
+    assert lib.sdmi_abi_version() == 3
     for name in declared:
         assert hasattr(lib, name)
 
@@ -35,7 +35,8 @@ def test_ctypes_struct_layout_matches_header():
 #include "sdmi.h"
 int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg), offsetof(sdmi_unet_cfg, context_dim),
  sizeof(sdmi_igemm_desc), offsetof(sdmi_igemm_desc, w), offsetof(sdmi_igemm_desc, seg_dst), offsetof(sdmi_igemm_desc, dma),
- offsetof(sdmi_igemm_desc, asym_pad), sizeof(sdmi_vae_cfg), offsetof(sdmi_vae_cfg, embed_dim)); }
+ offsetof(sdmi_igemm_desc, asym_pad), sizeof(sdmi_vae_cfg), offsetof(sdmi_vae_cfg, embed_dim));
+ printf("%zu %zu\n", sizeof(sdmi_clip_cfg), offsetof(sdmi_clip_cfg, max_positions)); }
 '''
     d = os.path.join(ROOT, 'stable-diffusion_amd', 'build')
     os.makedirs(d, exist_ok=True)
@@ -46,7 +47,7 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(_lib.UNetCfg), _lib.UNetCfg.context_dim.offset, C.sizeof(_lib.IGemmDesc), _lib.IGemmDesc.w.offset,
             _lib.IGemmDesc.seg_dst.offset, _lib.IGemmDesc.dma.offset, _lib.IGemmDesc.asym_pad.offset,
-            C.sizeof(_lib.VaeCfg), _lib.VaeCfg.embed_dim.offset]
+            C.sizeof(_lib.VaeCfg), _lib.VaeCfg.embed_dim.offset, C.sizeof(_lib.ClipCfg), _lib.ClipCfg.max_positions.offset]
     assert got == want
 
 
@@ -85,6 +86,29 @@ def test_vae_shim_has_reference_parameter_names():
         m.decode(torch.zeros(1, 4, 8, 8))
     with pytest.raises(NotImplementedError):
         AutoencoderKLHIP(dict(TINY_VAE.ddconfig(), attn_resolutions=[16]), None, 4)
+
+
+def test_clip_shim_has_checkpoint_parameter_names():
+    """FrozenCLIPEmbedderHIP.state_dict() == the `cond_stage_model.*` sub-tree of an SD-v1 checkpoint: transformers 4.19.2
+    CLIPTextModel names (oracle.clip_ref.clip_param_specs, pinned to Hugging Face's model by make_golden_clip) + the
+    persistent position_ids buffer."""
+    from oracle import clip_ref
+    from stable_diffusion_amd import FrozenCLIPEmbedderHIP
+    tc = dict(vocab_size=1000, hidden_size=128, intermediate_size=512, num_hidden_layers=2, num_attention_heads=2,
+              max_position_embeddings=77)
+    m = FrozenCLIPEmbedderHIP(text_config=tc, tokenizer=object())
+    mine = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    ref = {'transformer.' + k: tuple(s) for k, s, _ in clip_ref.clip_param_specs(clip_ref.TINY_CLIP)}
+    ref['transformer.text_model.embeddings.position_ids'] = (1, 77)
+    assert mine == ref
+    from stable_diffusion_amd.clip import CLIP_VIT_L14_TEXT, _ClipHandle, make_clip_cfg
+    specs = _ClipHandle(make_clip_cfg(CLIP_VIT_L14_TEXT)).weight_specs()
+    assert {k: tuple(s) for k, s in specs} == {k: tuple(s) for k, s, _ in clip_ref.clip_param_specs(clip_ref.SD_CLIP)}
+    assert len(specs) == 196
+    with pytest.raises(RuntimeError, match='no CPU'):
+        m.encode_ids(torch.zeros(1, 77, dtype=torch.long))
+    with pytest.raises(NotImplementedError):
+        FrozenCLIPEmbedderHIP(text_config=dict(tc, hidden_act='gelu'), tokenizer=object())
 
 
 def test_shim_refuses_cpu_tensors_and_foreign_configs():

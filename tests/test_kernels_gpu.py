@@ -250,6 +250,23 @@ def test_attention(d, heads, nq, nkv):
     assert K.report(f'attention d{d} nq{nq} nkv{nkv}', out, ref, 3e-3) < 3e-3
 
 
+@pytest.mark.parametrize('d,heads,n', [(64, 12, 77), (64, 2, 40), (32, 4, 130)])
+def test_attention_causal(d, heads, n):
+    """CLIPTextModel self-attention: softmax over keys <= query (transformers modeling_clip.py, causal mask)."""
+    g = _g(41)
+    B = 2
+    q = _rand16((B * heads, n, d), g); k = _rand16((B * heads, n, d), g); v = _rand16((B * heads, n, d), g)
+    scale = d ** -0.5
+    mask = torch.full((n, n), float('-inf')).triu(1)
+    p = torch.softmax(q.float() @ k.float().transpose(1, 2) * scale + mask, dim=-1)
+    ref = (p @ v.float()).reshape(B, heads, n, d).permute(0, 2, 1, 3).reshape(B, n, heads * d)
+    npad = (n + 7) // 8 * 8
+    vt = torch.zeros((B * heads, d, npad), dtype=torch.float16)
+    vt[:, :, :n] = v.transpose(1, 2)
+    out = K.attention_causal(q.to(DEV), k.to(DEV), vt.to(DEV), heads, scale)
+    assert K.report(f'attention causal d{d} n{n}', out, ref, 4e-3) < 4e-3
+
+
 @pytest.mark.parametrize('c0,c1,HW,silu,eps', [(320, 0, 64 * 64, 1, 1e-5), (1280, 640, 16 * 16, 1, 1e-5),
                                                (64, 0, 4, 0, 1e-6), (640, 320, 100, 1, 1e-5), (2560, 0, 64, 1, 1e-5)])
 def test_groupnorm(c0, c1, HW, silu, eps):

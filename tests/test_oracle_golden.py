@@ -123,3 +123,17 @@ def test_oracle_vae_encode_matches_reference_golden(case, golden_dir):
     ref = torch.from_numpy(z['moments'])
     assert mom.shape == ref.shape
     assert (mom - ref).abs().max().item() < 5e-5
+
+
+# ---- text encoder: oracle/clip_ref.py against Hugging Face CLIPTextModel goldens ------------------------
+@pytest.mark.parametrize('case', ['tiny_b2', 'tiny_b3_L40', 'sd_b2'])
+def test_oracle_clip_matches_hf_golden(case, golden_dir):
+    from oracle import clip_ref
+    z = np.load(os.path.join(golden_dir, f'clip_{case}.npz'))
+    cfg = {'tiny': clip_ref.TINY_CLIP, 'sd': clip_ref.SD_CLIP}[str(z['cfg'])]
+    sd = clip_ref.make_clip_state_dict(cfg, int(z['weight_seed']))
+    ids = clip_ref.make_clip_ids(cfg, int(z['batch']), int(z['L']), seed=int(z['input_seed']))
+    out = clip_ref.clip_text_forward(sd, cfg, ids)
+    ref = torch.from_numpy(z['out'])
+    assert out.shape == ref.shape and float(ref.abs().max()) > 2.0
+    assert (out - ref).abs().max().item() < 5e-5
