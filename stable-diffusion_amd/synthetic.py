@@ -63,6 +63,25 @@ def synthetic_vae_state_dict(ddconfig, embed_dim=4, seed=0):
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
+@torch.no_grad()
+def synthetic_clip_state_dict(text_config=None, seed=0):
+    """CPU state_dict (keys `transformer.text_model.*`, as under `cond_stage_model.` in an SD checkpoint) of a seeded
+    random CLIP text tower."""
+    from .clip import FrozenCLIPEmbedderHIP
+    m = FrozenCLIPEmbedderHIP(text_config=text_config, tokenizer=object())
+    g = torch.Generator().manual_seed(seed)
+    for name, p in m.named_parameters():
+        if 'embedding' in name:
+            p.copy_(torch.randn(p.shape, generator=g) * 0.5)
+        elif name.endswith('.weight') and p.dim() == 2:
+            p.copy_(torch.randn(p.shape, generator=g) / math.sqrt(p.shape[1]))
+        elif name.endswith('.weight'):
+            p.copy_(1.0 + 0.1 * torch.randn(p.shape, generator=g))
+        else:
+            p.copy_(0.02 * torch.randn(p.shape, generator=g))
+    return {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+
 SD_V1_UNET_KWARGS = dict(image_size=32, in_channels=4, out_channels=4, model_channels=320,
                          attention_resolutions=[4, 2, 1], num_res_blocks=2, channel_mult=[1, 2, 4, 4], num_heads=8,
                          use_spatial_transformer=True, transformer_depth=1, context_dim=768, use_checkpoint=True,

@@ -203,3 +203,16 @@ def test_plugin_seam_against_the_real_reference():
     assert isinstance(mine, AutoencoderKLHIP)
     assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == ref_keys
     assert len(ref_keys) == 248
+    # cond stage: `instantiate_from_config(cond_stage_config)` (ddpm.py:509-520); the yaml passes no params, the class
+    # defaults are the reference's (version / device / max_length, modules.py:139)
+    cs_cfg = cfg['model']['params']['cond_stage_config']
+    assert cs_cfg['target'] == 'ldm.modules.encoders.modules.FrozenCLIPEmbedder'
+    with torch.device('meta'):
+        mine = instantiate_from_config(dict(cs_cfg, target='stable_diffusion_amd.clip.FrozenCLIPEmbedderHIP'))
+    from oracle import clip_ref
+    from stable_diffusion_amd import FrozenCLIPEmbedderHIP
+    assert isinstance(mine, FrozenCLIPEmbedderHIP) and mine.max_length == 77 and mine.device == 'cuda'
+    want = {'transformer.' + k: tuple(s) for k, s, _ in clip_ref.clip_param_specs(clip_ref.SD_CLIP)}
+    want['transformer.text_model.embeddings.position_ids'] = (1, 77)
+    assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == want
+    assert hasattr(mine, 'encode') and hasattr(mine, 'freeze')

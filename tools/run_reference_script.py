@@ -11,8 +11,9 @@ What this launcher does (nothing in the reference tree is edited or copied):
     checkpoint's key names (`model.diffusion_model.*`, `first_stage_model.*`) -- there is no SD checkpoint in the
     environment; a real `--ckpt path` is loaded as usual;
   * `--hip`: writes a patched copy of the reference's `v1-inference.yaml` (only `unet_config.target` changed to
-    `stable_diffusion_amd.unet.UNetModelHIP` and `first_stage_config.target` to
-    `stable_diffusion_amd.vae.AutoencoderKLHIP`) to a temp file, passes it as `--config`, and swaps
+    `stable_diffusion_amd.unet.UNetModelHIP`, `first_stage_config.target` to
+    `stable_diffusion_amd.vae.AutoencoderKLHIP` and `cond_stage_config.target` to
+    `stable_diffusion_amd.clip.FrozenCLIPEmbedderHIP`) to a temp file, passes it as `--config`, and swaps
     `ldm.models.diffusion.plms.PLMSSampler` / `ddim.DDIMSampler` for the HIP samplers before the script imports them;
   * on a GPU-less host (BASELINE.json configs[0], the CPU plumbing check) it neutralises the hard-coded
     `.cuda()` / `torch.device("cuda")` uses (`txt2img.py:64`, `plms.py:18-22`); use `--precision full` there.
@@ -186,17 +187,22 @@ def install_stubs(have_gpu):
         nn.Module.cuda = lambda self, device=None: self
 
 
+HIP_COND_STAGE = False
+
+
 def patch_torch_load():
     real = torch.load
 
     def load(f, *a, **k):
         if isinstance(f, str) and f.startswith('synthetic'):
             seed = int(f.split(':')[1]) if ':' in f else 0
-            from stable_diffusion_amd.synthetic import (SD_V1_UNET_KWARGS, SD_V1_VAE_DDCONFIG, synthetic_state_dict,
-                                                        synthetic_vae_state_dict)
+            from stable_diffusion_amd.synthetic import (SD_V1_UNET_KWARGS, SD_V1_VAE_DDCONFIG, synthetic_clip_state_dict,
+                                                        synthetic_state_dict, synthetic_vae_state_dict)
             sd = {'model.diffusion_model.' + key: v for key, v in synthetic_state_dict(SD_V1_UNET_KWARGS, seed).items()}
             sd.update({'first_stage_model.' + key: v
                        for key, v in synthetic_vae_state_dict(SD_V1_VAE_DDCONFIG, 4, seed).items()})
+            if HIP_COND_STAGE:     # the reference's own FrozenCLIPEmbedder gets its (stand-in) weights from from_pretrained
+                sd.update({'cond_stage_model.' + key: v for key, v in synthetic_clip_state_dict(None, seed).items()})
             return {'state_dict': sd}
         return real(f, *a, **k)
     torch.load = load
@@ -229,6 +235,11 @@ def main():
         old = 'target: ldm.modules.diffusionmodules.openaimodel.UNetModel'
         assert old in text
         tmp = tempfile.NamedTemporaryFile('w', suffix='-mi355x.yaml', delete=False)
+        global HIP_COND_STAGE
+        HIP_COND_STAGE = True
+        old_clip = 'target: ldm.modules.encoders.modules.FrozenCLIPEmbedder'
+        assert old_clip in text
+        text = text.replace(old_clip, 'target: stable_diffusion_amd.clip.FrozenCLIPEmbedderHIP')
         old_vae = 'target: ldm.models.autoencoder.AutoencoderKL'
         assert old_vae in text
         text = text.replace(old_vae, 'target: stable_diffusion_amd.vae.AutoencoderKLHIP')
