@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 3
+#define SDMI_ABI_VERSION 4
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -86,6 +86,14 @@ int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float*
                       const float* old1, const float* old2, float a_t, float a_prev, float sigma, float sqrt_1m_at,
                       const float* noise, float* e_t_out, float* x_prev, float* pred_x0, int64_t n, void* stream);
 
+
+/* DPM-Solver++ (2M) step as `scripts/txt2img.py --dpm_solver` runs it: classifier-free combine
+ * (dpm_solver.py:340-346), data prediction m0 = (x - sigma_s e) / alpha_s (:386-399) and the multistep update
+ * order 1: x_next = cx x - a m0 (:519-530);  order 2: x_next = cx x - a m0 - 0.5 a inv_r0 (m0 - m_prev) (:776-790).
+ * m_out (optional) receives m0; x_next may be NULL (model value only). */
+int sdmi_dpm_solver_step(const float* eps_model, int cfg, float scale, const float* x, const float* m_prev, float alpha_s,
+                         float sigma_s, float cx, float a, float inv_r0, int order, float* m_out, float* x_next, int64_t n,
+                         void* stream);
 
 /* ---- first stage (AutoencoderKL): SURVEY.md 8 f-1 ---------------------------------------------------------------
  * Replaces instantiate_from_config(first_stage_config) (ddpm.py:462-467) for inference:

@@ -130,3 +130,95 @@ def ddim_decode(apply_model, alphas_cumprod, S, x_latent, c, t_start, scale=1.0,
     ts = make_ddim_timesteps(S, len(alphas_cumprod))
     tabs = make_sampling_tables(alphas_cumprod, ts, 0.0)
     return _ddim_loop(apply_model, tabs, ts[:t_start], x_latent, c, scale, uc, None, record)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# DPM-Solver++ (2M) as `scripts/txt2img.py --dpm_solver` runs it -- SURVEY.md 8 f-3
+#   DPMSolverSampler.sample            ldm/models/diffusion/dpm_solver/sampler.py:20-82
+#   NoiseScheduleVP('discrete')        dpm_solver.py:96-108,125-156 (+ interpolate_fn :1132-1171)
+#   model_wrapper (classifier-free)    dpm_solver.py:278-296,321-346
+#   DPM_Solver(predict_x0=True).sample(steps=S, skip_type='time_uniform', method='multistep', order=2,
+#                                      lower_order_final=True)          dpm_solver.py:386-399,504-530,755-790,1068-1096
+# ------------------------------------------------------------------------------------------------------------------
+def _interp(x, xp, yp):
+    """interpolate_fn (dpm_solver.py:1132-1171) for one channel: piecewise linear through (xp, yp), the outermost
+    segments extended beyond the key points; x [N], xp / yp [K] (xp ascending)."""
+    K = xp.shape[0]
+    idx = torch.searchsorted(xp.contiguous(), x.contiguous(), right=False)       # number of key points < x
+    lo = torch.clamp(idx - 1, 0, K - 2)
+    x0, x1, y0, y1 = xp[lo], xp[lo + 1], yp[lo], yp[lo + 1]
+    return y0 + (x - x0) * (y1 - y0) / (x1 - x0)
+
+
+class DiscreteVPSchedule:
+    """The members of NoiseScheduleVP(schedule='discrete', alphas_cumprod=...) the sampler touches."""
+
+    def __init__(self, alphas_cumprod):
+        ac = torch.as_tensor(np.asarray(alphas_cumprod), dtype=torch.float32)
+        self.total_N = ac.shape[0]
+        self.T = 1.0
+        self.t_array = torch.linspace(0., 1., self.total_N + 1)[1:]
+        self.log_alpha_array = 0.5 * torch.log(ac)
+
+    def log_alpha(self, t):
+        return _interp(t.reshape(-1), self.t_array, self.log_alpha_array)
+
+    def alpha(self, t):
+        return torch.exp(self.log_alpha(t))
+
+    def sigma(self, t):
+        return torch.sqrt(1. - torch.exp(2. * self.log_alpha(t)))
+
+    def lam(self, t):
+        la = self.log_alpha(t)
+        return la - 0.5 * torch.log(1. - torch.exp(2. * la))
+
+
+def dpm_solver_sample(apply_model, alphas_cumprod, S, x_T, c, scale=1.0, uc=None, record=None):
+    """x after S steps of multistep DPM-Solver++(2M), time-uniform steps from t = 1 to t = 1/N."""
+    ns = DiscreteVPSchedule(alphas_cumprod)
+    B = x_T.shape[0]
+    ts = torch.linspace(ns.T, 1. / ns.total_N, S + 1)
+    assert S >= 2
+
+    def model(x, t):                                   # data prediction with classifier-free guidance
+        tv = t.expand(B)
+        t_in = (tv - 1. / ns.total_N) * 1000.          # float model time, dpm_solver.py:284-285
+        if record is not None:
+            record.append(float(t_in[0]))
+        if uc is None or scale == 1.0:
+            e = apply_model(x, t_in, c)
+        else:
+            e_u, e_c = apply_model(torch.cat([x] * 2), torch.cat([t_in] * 2), torch.cat([uc, c])).chunk(2)
+            e = e_u + scale * (e_c - e_u)
+        a, s = ns.alpha(tv).view(-1, 1, 1, 1), ns.sigma(tv).view(-1, 1, 1, 1)
+        return (x - s * e) / a
+
+    def first(x, s_, t_, m):                           # dpm_solver_first_update, predict_x0 branch
+        h = ns.lam(t_) - ns.lam(s_)
+        return (ns.sigma(t_) / ns.sigma(s_)).view(-1, 1, 1, 1) * x - (ns.alpha(t_) * torch.expm1(-h)).view(-1, 1, 1, 1) * m
+
+    def second(x, m1, m0, t1, t0, t_):                 # multistep_dpm_solver_second_update, predict_x0 / 'dpm_solver'
+        l1, l0, lt = ns.lam(t1), ns.lam(t0), ns.lam(t_)
+        h0, h = l0 - l1, lt - l0
+        r0 = h0 / h
+        D1 = (1. / r0).view(-1, 1, 1, 1) * (m0 - m1)
+        a = (ns.alpha(t_) * (torch.exp(-h) - 1.)).view(-1, 1, 1, 1)
+        return (ns.sigma(t_) / ns.sigma(t0)).view(-1, 1, 1, 1) * x - a * m0 - 0.5 * a * D1
+
+    x = x_T
+    t_prev = [ts[0].expand(B)]
+    m_prev = [model(x, ts[0])]
+    x = first(x, t_prev[0], ts[1].expand(B), m_prev[0])
+    t_prev.append(ts[1].expand(B))
+    m_prev.append(model(x, ts[1]))
+    for step in range(2, S + 1):
+        vt = ts[step].expand(B)
+        order = min(2, S + 1 - step) if S < 15 else 2   # lower_order_final
+        if order == 2:
+            x = second(x, m_prev[0], m_prev[1], t_prev[0], t_prev[1], vt)
+        else:
+            x = first(x, t_prev[1], vt, m_prev[1])
+        t_prev = [t_prev[1], vt]
+        m_prev = [m_prev[1], model(x, ts[step]) if step < S else m_prev[1]]
+    return x

@@ -58,6 +58,8 @@ _SIGS = {
                                     c_ptr, C.c_int64, c_ptr]),
     'sdmi_sampler_step': (C.c_int, [c_ptr, C.c_int, C.c_float, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr, C.c_float,
                                     C.c_float, C.c_float, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_dpm_solver_step': (C.c_int, [c_ptr, C.c_int, C.c_float, c_ptr, c_ptr, C.c_float, C.c_float, C.c_float, C.c_float,
+                                       C.c_float, C.c_int, c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_vae_create': (C.c_int, [C.POINTER(VaeCfg), C.c_int, C.POINTER(c_ptr)]),
     'sdmi_vae_destroy': (C.c_int, [c_ptr]),
     'sdmi_vae_num_weights': (C.c_int, [c_ptr]),
@@ -124,7 +126,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 3:
+        if lib.sdmi_abi_version() != 4:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -97,6 +97,15 @@ int sdmi_sampler_step(const float* eps_model, int cfg, float scale, const float*
 }
 
 
+int sdmi_dpm_solver_step(const float* eps_model, int cfg, float scale, const float* x, const float* m_prev, float alpha_s,
+                         float sigma_s, float cx, float a, float inv_r0, int order, float* m_out, float* x_next, int64_t n,
+                         void* stream) {
+  DpmStepParams p;
+  p.eps_model = eps_model; p.cfg = cfg; p.scale = scale; p.x = x; p.m_prev = m_prev; p.alpha_s = alpha_s; p.sigma_s = sigma_s;
+  p.cx = cx; p.a = a; p.inv_r0 = inv_r0; p.order = order; p.m_out = m_out; p.x_next = x_next; p.n = n;
+  return launch_dpm_step(p, (hipStream_t)stream);
+}
+
 // ---- first stage --------------------------------------------------------------------------------------
 int sdmi_vae_create(const sdmi_vae_cfg* cfg, int parts, sdmi_vae** out) {
   SDMI_CHECK(cfg && out, "null argument");

@@ -167,6 +167,21 @@ int launch_conv_in(const float* x_nchw, const float* w, const float* bias, float
 int launch_conv_out(const float* h_nhwc, const float* w_khwc, const float* bias, float* out_nchw, int B, int H, int W,
                     int Cin, int Cout, hipStream_t s);
 
+// DPM-Solver++ multistep step (see sampler.hip)
+struct DpmStepParams {
+  const float* eps_model = nullptr;  // model output: rows [0,n) uncond, [n,2n) cond when cfg, else [0,n)
+  int cfg = 0; float scale = 1.f;
+  const float* x = nullptr;          // latent the model was evaluated at
+  const float* m_prev = nullptr;     // previous data prediction (order 2)
+  float alpha_s = 1.f, sigma_s = 0.f;      // marginal alpha / std at the evaluation time
+  float cx = 1.f, a = 0.f, inv_r0 = 0.f;   // update coefficients
+  int order = 1;
+  float* m_out = nullptr;            // data prediction at this step (kept as history)
+  float* x_next = nullptr;           // optional: the updated latent
+  int64_t n = 0;
+};
+int launch_dpm_step(const DpmStepParams& p, hipStream_t s);
+
 // text-encoder helpers: out[m][:] = tok_emb[ids[m]][:] + pos_emb[m % L][:] (fp32); out16 = fp16(x * sigmoid(1.702 x))
 int launch_embed_tokens(const int64_t* ids, const float* tok_emb, const float* pos_emb, float* out, int M, int L, int C,
                         int vocab, hipStream_t s);

@@ -1,6 +1,7 @@
-"""`PLMSSamplerHIP` / `DDIMSamplerHIP` -- drop-ins for the reference samplers
-(ldm/models/diffusion/plms.py PLMSSampler, ddim.py DDIMSampler): same constructor, `make_schedule`,
-`sample(...) -> (samples, intermediates)`, and for DDIM `stochastic_encode` / `decode` (scripts/img2img.py:237-262).
+"""`PLMSSamplerHIP` / `DDIMSamplerHIP` / `DPMSolverSamplerHIP` -- drop-ins for the reference samplers
+(ldm/models/diffusion/plms.py PLMSSampler, ddim.py DDIMSampler, dpm_solver/sampler.py DPMSolverSampler): same
+constructor, `make_schedule`, `sample(...) -> (samples, intermediates)`, and for DDIM `stochastic_encode` / `decode`
+(scripts/img2img.py:237-262).
 
 Per step the reference issues ~15 elementwise launches plus four `torch.full` from host scalars
 (plms.py:178-236); here the classifier-free-guidance combine and the PLMS/DDIM latent update are one fused
@@ -111,12 +112,12 @@ class _SamplerBase(object):
             c_in, x_in = cond, torch.empty(tuple(shape), device=device, dtype=torch.float32)
         return device, b, img, cfg, c_in, x_in
 
-    def _model_eps(self, x_in, img, t_val, c_in, cfg, b):
+    def _model_eps(self, x_in, img, t_val, c_in, cfg, b, t_dtype=torch.long):
         """apply_model on the (duplicated) latent; returns the raw model output [2b or b, C, H, W] fp32."""
         x_in[:b].copy_(img)
         if cfg:
             x_in[b:].copy_(img)
-        t_in = torch.full((x_in.shape[0],), t_val, device=x_in.device, dtype=torch.long)
+        t_in = torch.full((x_in.shape[0],), t_val, device=x_in.device, dtype=t_dtype)
         out = self.model.apply_model(x_in, t_in, c_in)
         return out.float().contiguous()
 
@@ -290,3 +291,101 @@ class DDIMSamplerHIP(_SamplerBase):
         img, _ = self._loop(cond, tuple(x_latent.shape), self.ddim_timesteps[:t_start], x_T=x_latent,
                             scale=unconditional_guidance_scale, uc=unconditional_conditioning, desc='Decoding image')
         return img
+
+
+# ---- DPM-Solver++ (2M): scripts/txt2img.py --dpm_solver ----------------------------------------------
+class _DiscreteVP:
+    """Host-side subset of NoiseScheduleVP('discrete', alphas_cumprod=...) (dpm_solver.py:96-156): log alpha_t is the
+    piecewise-linear interpolant of 0.5 log(alphas_cumprod) over t_n = n / N, n = 1..N; fp32 torch ops on the CPU, in the
+    reference's order, so the step coefficients equal the reference's."""
+
+    def __init__(self, alphas_cumprod):
+        ac = alphas_cumprod.detach().to(torch.float32).cpu()
+        self.N = ac.shape[0]
+        self.t_array = torch.linspace(0., 1., self.N + 1)[1:]
+        self.log_alpha_array = 0.5 * torch.log(ac)
+
+    def log_alpha(self, t):
+        xp, yp = self.t_array, self.log_alpha_array
+        i = int(torch.clamp(torch.searchsorted(xp, t.reshape(1)) - 1, 0, self.N - 2))
+        return yp[i] + (t - xp[i]) * (yp[i + 1] - yp[i]) / (xp[i + 1] - xp[i])
+
+    def alpha(self, t):
+        return torch.exp(self.log_alpha(t))
+
+    def sigma(self, t):
+        return torch.sqrt(1. - torch.exp(2. * self.log_alpha(t)))
+
+    def lam(self, t):
+        la = self.log_alpha(t)
+        return la - 0.5 * torch.log(1. - torch.exp(2. * la))
+
+
+def dpm_plan(ns, S):
+    """Per model evaluation k = 0..S-1 (at time t_k, stepping to t_{k+1}; time-uniform from 1 to 1/N):
+    (t_input, alpha_s, sigma_s, order, cx, a, inv_r0) for sdmi_dpm_solver_step -- DPM_Solver.sample(method='multistep',
+    order=2, lower_order_final=True), dpm_solver.py:1068-1096."""
+    if S < 2:
+        raise ValueError('multistep DPM-Solver of order 2 needs at least 2 steps')      # `assert steps >= order`
+    ts = torch.linspace(1., 1. / ns.N, S + 1)
+    plan = []
+    for k in range(S):
+        s_, t_ = ts[k], ts[k + 1]
+        step = k + 1
+        order = 1 if step == 1 else (min(2, S + 1 - step) if S < 15 else 2)
+        cx = ns.sigma(t_) / ns.sigma(s_)
+        if order == 1:
+            h = ns.lam(t_) - ns.lam(s_)
+            a = ns.alpha(t_) * torch.expm1(-h)
+            inv_r0 = torch.zeros(())
+        else:
+            l1, l0, lt = ns.lam(ts[k - 1]), ns.lam(s_), ns.lam(t_)
+            h0, h = l0 - l1, lt - l0
+            inv_r0 = 1. / (h0 / h)
+            a = ns.alpha(t_) * (torch.exp(-h) - 1.)
+        t_input = (s_ - 1. / ns.N) * 1000.
+        plan.append((float(t_input), float(ns.alpha(s_)), float(ns.sigma(s_)), order, float(cx), float(a), float(inv_r0)))
+    return plan
+
+
+class DPMSolverSamplerHIP(_SamplerBase):
+    """dpm_solver/sampler.py:9-82: `sample(...)` returns (x, None)."""
+
+    def __init__(self, model, **kwargs):
+        super().__init__(model, **kwargs)
+        self.alphas_cumprod = model.alphas_cumprod.detach().to(torch.float32)
+
+    @torch.no_grad()
+    def sample(self, S, batch_size, shape, conditioning=None, callback=None, normals_sequence=None, img_callback=None,
+               quantize_x0=False, eta=0., mask=None, x0=None, temperature=1., noise_dropout=0., score_corrector=None,
+               corrector_kwargs=None, verbose=True, x_T=None, log_every_t=100, unconditional_guidance_scale=1.,
+               unconditional_conditioning=None, **kwargs):
+        if isinstance(conditioning, dict):
+            raise NotImplementedError('dict conditioning (hybrid models) is outside the SD-v1 txt2img path')
+        if conditioning is not None and conditioning.shape[0] != batch_size:
+            print(f'Warning: Got {conditioning.shape[0]} conditionings but batch-size is {batch_size}')
+        C, H, W = shape
+        scale, uc = unconditional_guidance_scale, unconditional_conditioning
+        device, b, img, cfg, c_in, x_in = self._prepare(conditioning, (batch_size, C, H, W), x_T, uc, scale)
+        if not img.is_cuda:
+            raise RuntimeError('the HIP sampler step runs on MI355X device tensors only (no CPU fallback)')
+        plan = dpm_plan(_DiscreteVP(self.alphas_cumprod), S)
+        lib = _lib.load()
+        unet = self._hip_unet()
+        if unet is not None:
+            unet.pin_context(c_in)
+        try:
+            m_prev = None
+            for k, (t_input, alpha_s, sigma_s, order, cx, a, inv_r0) in enumerate(plan):
+                eps = self._model_eps(x_in, img, t_input, c_in, cfg, b, t_dtype=torch.float32)
+                m_new, x_next = torch.empty_like(img), torch.empty_like(img)
+                _lib.check(lib.sdmi_dpm_solver_step(eps.data_ptr(), int(cfg), float(scale), img.data_ptr(), _lib.ptr(m_prev),
+                                                    alpha_s, sigma_s, cx, a, inv_r0, order, m_new.data_ptr(),
+                                                    x_next.data_ptr(), img.numel(), _lib.stream_ptr()))
+                m_prev, img = m_new, x_next
+                if callback: callback(k)
+                if img_callback: img_callback(m_new, k)
+        finally:
+            if unet is not None:
+                unet.unpin_context()
+        return img, None

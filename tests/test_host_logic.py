@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 3
+    assert lib.sdmi_abi_version() == 4
     for name in declared:
         assert hasattr(lib, name)
 
@@ -152,6 +152,38 @@ def test_sampler_tables_and_plan_match_oracle():
     assert plan[-1][:4] == (49, 0, 1, 1)        # last step: t_next == t (plms.py:145)
     with pytest.raises(ValueError):
         samplers.PLMSSamplerHIP(type('M', (), {'num_timesteps': 1000})()).make_schedule(10, ddim_eta=0.5)
+
+
+def test_dpm_solver_plan_reproduces_the_reference(golden_dir):
+    """The host-side DPM-Solver++ plan (schedule interpolation, step orders incl. lower_order_final, coefficients) driven
+    through a torch emulation of sdmi_dpm_solver_step's arithmetic reproduces the reference DPMSolverSampler's end points
+    exactly (same fp32 ops in the same order on the same CPU)."""
+    from stable_diffusion_amd.samplers import _DiscreteVP, dpm_plan
+    D = np.load(os.path.join(golden_dir, 'dpm_solver.npz'))
+    ac = torch.from_numpy(D['alphas_cumprod'])
+    x_T, c, uc = (torch.from_numpy(D[k]) for k in ('x_T', 'c', 'uc'))
+
+    def stub(x, t, cc):
+        return torch.tanh(0.7 * x + 0.001 * t.float()[:, None, None, None]) * 0.9 + 0.05 * cc.mean(dim=(1, 2))[:, None, None, None]
+    for S, scale, ucond in ((20, 7.5, uc), (10, 7.5, uc), (50, 5.0, uc), (12, 1.0, None)):
+        plan = dpm_plan(_DiscreteVP(ac), S)
+        assert [p[3] for p in plan] == [1] + [2] * (S - 2) + [1 if S < 15 else 2]
+        x, m_prev = x_T.clone(), None
+        for (t_in, al, sg, order, cx, a, ir) in plan:
+            tt = torch.full((2,), t_in)
+            if ucond is None:
+                e = stub(x, tt, c)
+            else:
+                eu, ec = stub(torch.cat([x] * 2), torch.cat([tt] * 2), torch.cat([ucond, c])).chunk(2)
+                e = eu + scale * (ec - eu)
+            m0 = (x - sg * e) / al
+            xt = cx * x - a * m0
+            if order == 2:
+                xt = xt - (0.5 * a) * (ir * (m0 - m_prev))
+            m_prev, x = m0, xt
+        assert torch.equal(x, torch.from_numpy(D[f'dpm_{S}_{scale}']))
+    with pytest.raises(ValueError):
+        dpm_plan(_DiscreteVP(ac), 1)
 
 
 def test_ldm_shim_schedule_equals_oracle():

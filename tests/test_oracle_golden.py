@@ -137,3 +137,14 @@ def test_oracle_clip_matches_hf_golden(case, golden_dir):
     ref = torch.from_numpy(z['out'])
     assert out.shape == ref.shape and float(ref.abs().max()) > 2.0
     assert (out - ref).abs().max().item() < 5e-5
+
+
+# ---- DPM-Solver++ (2M): oracle loop against the reference DPMSolverSampler's end points -------------------
+@pytest.mark.parametrize('S,scale,cfg', [(20, 7.5, True), (10, 7.5, True), (50, 5.0, True), (12, 1.0, False)])
+def test_oracle_dpm_solver_matches_reference_golden(golden_dir, S, scale, cfg):
+    D = np.load(os.path.join(golden_dir, 'dpm_solver.npz'))
+    x_T, c, uc = (torch.from_numpy(D[k]) for k in ('x_T', 'c', 'uc'))
+    rec = []
+    out = samplers_ref.dpm_solver_sample(_stub, D['alphas_cumprod'], S, x_T, c, scale, uc if cfg else None, record=rec)
+    assert len(rec) == S and abs(rec[0] - 999.0) < 1e-3
+    assert (out - torch.from_numpy(D[f'dpm_{S}_{scale}'])).abs().max().item() < 1e-5

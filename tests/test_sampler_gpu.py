@@ -139,3 +139,55 @@ def test_img2img_end_to_end_with_hip_unet():
     err = (out.cpu() - ref).abs().max().item()
     print(f'[img2img e2e tiny] max-abs {err:.3e}')
     assert err < 3e-2
+
+
+# ---- DPM-Solver++ (2M): scripts/txt2img.py --dpm_solver -------------------------------------------
+@pytest.mark.parametrize('S,scale,cfg', [(20, 7.5, True), (10, 7.5, True), (50, 5.0, True), (12, 1.0, False)])
+def test_dpm_solver_trajectory(golden_dir, S, scale, cfg):
+    """DPMSolverSamplerHIP against the reference DPMSolverSampler's end point (tests/golden/dpm_solver.npz,
+    oracle/make_golden_dpm.py); S = 10 / 12 exercise lower_order_final, S = 12 the guidance-free branch."""
+    from stable_diffusion_amd import DPMSolverSamplerHIP
+    D = np.load(os.path.join(golden_dir, 'dpm_solver.npz'))
+    S0 = np.load(os.path.join(golden_dir, 'samplers.npz'))
+    model = StubLD(S0['betas'], D['alphas_cumprod'])
+    model.apply_model = lambda x, t, c: (model.calls.append(float(t[0])), stub_unet(x, t, c))[1]
+    x_T, c, uc = (torch.from_numpy(D[k]).cuda() for k in ('x_T', 'c', 'uc'))
+    out, none = DPMSolverSamplerHIP(model).sample(S=S, batch_size=2, shape=[4, 8, 8], conditioning=c, verbose=False, x_T=x_T,
+                                                  unconditional_guidance_scale=scale,
+                                                  unconditional_conditioning=uc if cfg else None)
+    ref = torch.from_numpy(D[f'dpm_{S}_{scale}'])
+    err = (out.cpu() - ref).abs().max().item()
+    print(f'[dpm-solver S={S} scale={scale}] calls {len(model.calls)} t_in {model.calls[0]:.2f} .. {model.calls[-1]:.2f} '
+          f'max-abs {err:.3e} (|x| max {ref.abs().max():.2f})')
+    assert none is None and len(model.calls) == S and abs(model.calls[0] - 999.0) < 1e-3
+    # GPU-vs-CPU tanh in the stub model (measured 1.5e-5 .. 2.7e-5 at |x| ~ 39)
+    assert err < 2e-4
+
+
+@pytest.mark.parametrize('order', [1, 2])
+@pytest.mark.parametrize('cfg', [0, 1])
+def test_dpm_step_bit_exact(order, cfg):
+    """sdmi_dpm_solver_step == the reference's torch expressions evaluated on the GPU (dpm_solver.py:340-346, :386-399,
+    :519-530, :776-790), bit for bit."""
+    import ctypes  # noqa: F401
+    from stable_diffusion_amd import _lib
+    g = torch.Generator().manual_seed(5)
+    n = 2 * 4 * 16 * 16
+    eps = torch.randn(2 * n if cfg else n, generator=g).cuda()
+    x = (torch.randn(n, generator=g) * 3).cuda()
+    m1 = torch.randn(n, generator=g).cuda()
+    alpha_s, sigma_s, cx, a, inv_r0, scale = 0.7341, 0.6790, 0.93127, -0.08123, 1.2345, 7.5
+    T = lambda v: torch.tensor(v, device='cuda')
+    e = eps[:n] + scale * (eps[n:] - eps[:n]) if cfg else eps
+    m0_ref = (x - T(sigma_s) * e) / T(alpha_s)
+    if order == 1:
+        xt_ref = T(cx) * x - T(a) * m0_ref
+    else:
+        D1 = T(inv_r0) * (m0_ref - m1)
+        xt_ref = T(cx) * x - T(a) * m0_ref - 0.5 * T(a) * D1
+    m0, xt = torch.empty_like(x), torch.empty_like(x)
+    _lib.check(_lib.load().sdmi_dpm_solver_step(eps.data_ptr(), cfg, scale, x.data_ptr(), m1.data_ptr() if order == 2 else None,
+                                                alpha_s, sigma_s, cx, a, inv_r0, order, m0.data_ptr(), xt.data_ptr(), n,
+                                                _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(m0, m0_ref) and torch.equal(xt, xt_ref)

@@ -14,7 +14,8 @@ What this launcher does (nothing in the reference tree is edited or copied):
     `stable_diffusion_amd.unet.UNetModelHIP`, `first_stage_config.target` to
     `stable_diffusion_amd.vae.AutoencoderKLHIP` and `cond_stage_config.target` to
     `stable_diffusion_amd.clip.FrozenCLIPEmbedderHIP`) to a temp file, passes it as `--config`, and swaps
-    `ldm.models.diffusion.plms.PLMSSampler` / `ddim.DDIMSampler` for the HIP samplers before the script imports them;
+    `ldm.models.diffusion.plms.PLMSSampler` / `ddim.DDIMSampler` / `dpm_solver.DPMSolverSampler` for the HIP samplers
+    before the script imports them;
   * on a GPU-less host (BASELINE.json configs[0], the CPU plumbing check) it neutralises the hard-coded
     `.cuda()` / `torch.device("cuda")` uses (`txt2img.py:64`, `plms.py:18-22`); use `--precision full` there.
 Then it `runpy`-executes the script with the remaining arguments.
@@ -228,8 +229,9 @@ def main():
     import ldm.models.diffusion.ddim as ddim
     import ldm.models.diffusion.plms as plms
     if args.hip:
-        from stable_diffusion_amd import DDIMSamplerHIP, PLMSSamplerHIP
-        plms.PLMSSampler, ddim.DDIMSampler = PLMSSamplerHIP, DDIMSamplerHIP
+        from stable_diffusion_amd import DDIMSamplerHIP, DPMSolverSamplerHIP, PLMSSamplerHIP
+        import ldm.models.diffusion.dpm_solver as dpm
+        plms.PLMSSampler, ddim.DDIMSampler, dpm.DPMSolverSampler = PLMSSamplerHIP, DDIMSamplerHIP, DPMSolverSamplerHIP
         src = os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')
         text = open(src).read()
         old = 'target: ldm.modules.diffusionmodules.openaimodel.UNetModel'
@@ -247,7 +249,8 @@ def main():
         tmp.close()
         rest = ['--config', tmp.name] + rest
     elif not have_gpu:
-        for cls in (plms.PLMSSampler, ddim.DDIMSampler):        # plms.py:18-22 hard-codes torch.device("cuda")
+        import ldm.models.diffusion.dpm_solver.sampler as dpm_s
+        for cls in (plms.PLMSSampler, ddim.DDIMSampler, dpm_s.DPMSolverSampler):   # plms.py:18-22 hard-codes torch.device("cuda")
             cls.register_buffer = lambda self, name, attr: setattr(self, name, attr)
     if not have_gpu:                                            # encoders/modules.py:139 defaults device="cuda"
         import ldm.modules.encoders.modules as enc
