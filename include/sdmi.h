@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 4
+#define SDMI_ABI_VERSION 5
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -57,6 +57,13 @@ int sdmi_unet_weight_info(const sdmi_unet* h, int idx, char* key_buf, int key_bu
 int sdmi_unet_set_weight(sdmi_unet* h, const char* key, const float* ptr, const int64_t* shape, int ndim, void* stream);
 /* fails (listing the first missing key) unless every expected tensor was set */
 int sdmi_unet_finalize(sdmi_unet* h);
+
+/* Packed-weight blob: the packed device buffers of a finalized handle, behind a header that pins the
+ * configuration and ABI version.  `import` replaces every set_weight call + finalize (no fp32 checkpoint, no repack);
+ * the buffers are host memory (e.g. an mmap of the file tools/pack_checkpoint.py writes). */
+int64_t sdmi_unet_packed_bytes(sdmi_unet* h);
+int sdmi_unet_export_packed(sdmi_unet* h, void* host_buf, int64_t bytes, void* stream);
+int sdmi_unet_import_packed(sdmi_unet* h, const void* host_buf, int64_t bytes, void* stream);
 
 /* bytes of scratch `sdmi_unet_forward` needs for this shape (0 on error) */
 int64_t sdmi_unet_workspace_bytes(sdmi_unet* h, int B, int H, int W, int Lctx);

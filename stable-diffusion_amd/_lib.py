@@ -52,6 +52,9 @@ _SIGS = {
     'sdmi_unet_weight_info': (C.c_int, [c_ptr, C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int)]),
     'sdmi_unet_set_weight': (C.c_int, [c_ptr, C.c_char_p, c_ptr, C.POINTER(C.c_int64), C.c_int, c_ptr]),
     'sdmi_unet_finalize': (C.c_int, [c_ptr]),
+    'sdmi_unet_packed_bytes': (C.c_int64, [c_ptr]),
+    'sdmi_unet_export_packed': (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_unet_import_packed': (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_unet_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int]),
     'sdmi_unet_cache_context': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
     'sdmi_unet_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -126,7 +129,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 4:
+        if lib.sdmi_abi_version() != 5:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

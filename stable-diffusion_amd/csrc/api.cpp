@@ -64,6 +64,21 @@ int sdmi_unet_set_weight(sdmi_unet* h, const char* key, const float* ptr, const 
 }
 int sdmi_unet_finalize(sdmi_unet* h) { SDMI_CHECK(h, "null handle"); return h->impl.finalize(); }
 
+int64_t sdmi_unet_packed_bytes(sdmi_unet* h) {
+  if (!h) { fail("null handle"); return 0; }
+  int64_t total = 0;
+  h->impl.packed_layout(nullptr, &total);
+  return total;
+}
+int sdmi_unet_export_packed(sdmi_unet* h, void* host_buf, int64_t bytes, void* stream) {
+  SDMI_CHECK(h && host_buf, "null argument");
+  return h->impl.export_packed(host_buf, bytes, (hipStream_t)stream);
+}
+int sdmi_unet_import_packed(sdmi_unet* h, const void* host_buf, int64_t bytes, void* stream) {
+  SDMI_CHECK(h && host_buf, "null argument");
+  return h->impl.import_packed(host_buf, bytes, (hipStream_t)stream);
+}
+
 int64_t sdmi_unet_workspace_bytes(sdmi_unet* h, int B, int H, int W, int Lctx) {
   if (!h) { fail("null handle"); return 0; }
   int64_t need = 0;

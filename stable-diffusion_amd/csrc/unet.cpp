@@ -226,6 +226,25 @@ int UNet::dev_alloc(void** dst, size_t bytes) {
   return 0;
 }
 
+// bytes of the packed device buffer a slot writes into (several slots may share one buffer: q|k|v rows, emb_layers rows)
+size_t UNet::slot_bytes(const WeightSlot& s) const {
+  size_t numel = 1;
+  for (int64_t d : s.shape) numel *= (size_t)d;
+  switch (s.kind) {
+    case W_F32: case W_CONV_OUT: case W_GEGLU_B: return numel * sizeof(float);
+    case W_F32_ROWS: return (size_t)emb_total_ * s.ld * sizeof(float);
+    case W_CONV: case W_GEGLU_W: return numel * sizeof(f16);
+    case W_SPLIT3: return 3 * numel * sizeof(f16);
+    case W_ROWS16: {
+      size_t total_rows = (size_t)s.shape[0];
+      if (s.key.find(".attn1.to_") != std::string::npos && s.key.find("to_out") == std::string::npos) total_rows *= 3;
+      if (s.key.find(".attn2.to_k") != std::string::npos || s.key.find(".attn2.to_v") != std::string::npos) total_rows *= 2;
+      return total_rows * s.ld * sizeof(f16);
+    }
+  }
+  return 0;
+}
+
 int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, int ndim, hipStream_t stream) {
   auto it = slot_index_.find(key);
   if (it == slot_index_.end()) return fail(std::string("unexpected weight key: ") + key);
@@ -242,47 +261,42 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
   int rc = 0;
   switch (s.kind) {
     case W_F32:
-      rc = dev_alloc(s.dst, numel * sizeof(float));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) SDMI_HIP_OK(hipMemcpyAsync(*s.dst, dptr, numel * sizeof(float), hipMemcpyDeviceToDevice, stream));
       break;
     case W_F32_ROWS: {   // rows of a concatenated fp32 matrix (the 22 emb_layers)
-      rc = dev_alloc(s.dst, (size_t)emb_total_ * s.ld * sizeof(float));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc)
         SDMI_HIP_OK(hipMemcpyAsync((float*)*s.dst + (size_t)s.row0 * s.ld, dptr, numel * sizeof(float),
                                    hipMemcpyDeviceToDevice, stream));
       break;
     }
     case W_CONV:
-      rc = dev_alloc(s.dst, numel * sizeof(f16));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_conv_weight(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], (int)shape[2], (int)shape[3], stream);
       break;
     case W_SPLIT3:
-      rc = dev_alloc(s.dst, 3 * numel * sizeof(f16));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_split3(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], stream);
       break;
     case W_CONV_OUT:
-      rc = dev_alloc(s.dst, numel * sizeof(float));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_conv_out(dptr, (float*)*s.dst, (int)shape[0], (int)shape[1], stream);
       break;
     case W_ROWS16: {     // rows [row0, row0+rows) of an fp16 [*, ld] matrix (q|k|v and k|v concatenations)
-      // total rows of the destination: qkv -> 3C, kv -> 2C, others -> rows; allocate by the largest user
       const int rows = (int)shape[0];
-      size_t total_rows = rows;
-      const std::string k(key);
-      if (k.find(".attn1.to_") != std::string::npos && k.find("to_out") == std::string::npos) total_rows = 3 * (size_t)rows;
-      if (k.find(".attn2.to_k") != std::string::npos || k.find(".attn2.to_v") != std::string::npos) total_rows = 2 * (size_t)rows;
-      rc = dev_alloc(s.dst, total_rows * s.ld * sizeof(f16));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_rows(dptr, (f16*)*s.dst, rows, (int)shape[1], s.row0, s.ld, stream);
       break;
     }
     case W_GEGLU_W: {
       // weight and bias arrive separately; the weight packer does not need the bias (and vice versa)
-      rc = dev_alloc(s.dst, numel * sizeof(f16));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_geglu(dptr, nullptr, (f16*)*s.dst, nullptr, (int)shape[0], (int)shape[1], stream);
       break;
     }
     case W_GEGLU_B: {
-      rc = dev_alloc(s.dst, numel * sizeof(float));
+      rc = dev_alloc(s.dst, slot_bytes(s));
       // permute the bias with the same 32-row interleave: reuse the packer with K = 1 on a [N][1] "matrix"
       if (!rc) {
         f16* tmp = nullptr;
@@ -311,6 +325,78 @@ int UNet::finalize() {
   }
   finalized_ = true;
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// packed-weight blob: the device buffers exactly as set_weight() leaves them, one after another
+// in slot order, behind a header that pins the configuration -- loading it skips the fp32 checkpoint and the repack
+// ------------------------------------------------------------------------------------------------------
+namespace {
+struct PackedHeader {
+  char magic[8];               // "SDMIPK01"
+  int32_t abi, precise_1x1, n_buffers, reserved;
+  sdmi_unet_cfg cfg;
+  int64_t total_bytes;
+};
+constexpr int64_t PK_ALIGN = 256;
+}  // namespace
+
+int UNet::packed_layout(std::vector<std::pair<void**, size_t>>* bufs, int64_t* total) const {
+  std::vector<void**> seen;
+  int64_t off = (int64_t)round_up((int64_t)sizeof(PackedHeader), PK_ALIGN);
+  for (const auto& s : slots_) {
+    if (std::find(seen.begin(), seen.end(), s.dst) != seen.end()) continue;
+    seen.push_back(s.dst);
+    const size_t b = slot_bytes(s);
+    if (bufs) bufs->push_back({s.dst, b});
+    off += (int64_t)round_up((int64_t)b, PK_ALIGN);
+  }
+  *total = off;
+  return 0;
+}
+
+int UNet::export_packed(void* host_buf, int64_t bytes, hipStream_t stream) {
+  SDMI_CHECK(finalized_, "export needs a finalized handle");
+  std::vector<std::pair<void**, size_t>> bufs;
+  int64_t total = 0;
+  packed_layout(&bufs, &total);
+  SDMI_CHECK(host_buf && bytes >= total, "packed buffer too small: need " + std::to_string(total) + " bytes");
+  PackedHeader h{};
+  memcpy(h.magic, "SDMIPK01", 8);
+  h.abi = SDMI_ABI_VERSION; h.precise_1x1 = precise_1x1_ ? 1 : 0; h.n_buffers = (int32_t)bufs.size(); h.cfg = cfg_;
+  h.total_bytes = total;
+  memcpy(host_buf, &h, sizeof(h));
+  int64_t off = (int64_t)round_up((int64_t)sizeof(PackedHeader), PK_ALIGN);
+  for (auto& b : bufs) {
+    SDMI_HIP_OK(hipMemcpyAsync((char*)host_buf + off, *b.first, b.second, hipMemcpyDeviceToHost, stream));
+    off += (int64_t)round_up((int64_t)b.second, PK_ALIGN);
+  }
+  SDMI_HIP_OK(hipStreamSynchronize(stream));
+  return 0;
+}
+
+int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream) {
+  SDMI_CHECK(host_buf && bytes >= (int64_t)sizeof(PackedHeader), "packed blob truncated");
+  PackedHeader h;
+  memcpy(&h, host_buf, sizeof(h));
+  SDMI_CHECK(memcmp(h.magic, "SDMIPK01", 8) == 0, "not a libsdmi packed-weight blob");
+  SDMI_CHECK(h.abi == SDMI_ABI_VERSION, "packed blob was written by a different ABI version: repack it");
+  SDMI_CHECK(memcmp(&h.cfg, &cfg_, sizeof(cfg_)) == 0, "packed blob was written for a different UNet configuration");
+  SDMI_CHECK((h.precise_1x1 != 0) == precise_1x1_, "packed blob was written with a different SDMI_PRECISE_1X1 setting");
+  std::vector<std::pair<void**, size_t>> bufs;
+  int64_t total = 0;
+  packed_layout(&bufs, &total);
+  SDMI_CHECK(h.n_buffers == (int32_t)bufs.size() && h.total_bytes == total && bytes >= total, "packed blob truncated or inconsistent");
+  int64_t off = (int64_t)round_up((int64_t)sizeof(PackedHeader), PK_ALIGN);
+  for (auto& b : bufs) {
+    if (dev_alloc(b.first, b.second)) return -1;
+    SDMI_HIP_OK(hipMemcpyAsync(*b.first, (const char*)host_buf + off, b.second, hipMemcpyHostToDevice, stream));
+    off += (int64_t)round_up((int64_t)b.second, PK_ALIGN);
+  }
+  SDMI_HIP_OK(hipStreamSynchronize(stream));
+  for (auto& s : slots_) s.set = true;
+  ctx_valid_ = false;
+  return finalize();
 }
 
 // ------------------------------------------------------------------------------------------------------

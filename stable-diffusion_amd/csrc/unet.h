@@ -2,6 +2,7 @@
 #pragma once
 #include <map>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/sdmi.h"
@@ -146,6 +147,10 @@ class UNet {
   int build(const sdmi_unet_cfg& cfg);
   int set_weight(const char* key, const float* ptr, const int64_t* shape, int ndim, hipStream_t stream);
   int finalize();
+  // packed-weight blob: every packed device buffer behind a header that pins cfg / ABI
+  int packed_layout(std::vector<std::pair<void**, size_t>>* bufs, int64_t* total) const;
+  int export_packed(void* host_buf, int64_t bytes, hipStream_t stream);
+  int import_packed(const void* host_buf, int64_t bytes, hipStream_t stream);
   // dry = size only; ctx_only = just the cross-attention K/V of every SpatialTransformer
   int run(const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx, float* eps_out, int B, int H, int W,
           int Lctx, void* workspace, int64_t ws_bytes, hipStream_t stream, bool dry, bool ctx_only, int64_t* bytes_needed);
@@ -168,6 +173,7 @@ class UNet {
   void expect(const std::string& key, std::vector<int64_t> shape, WKind kind, void** dst, int row0 = 0, int ld = 0,
               void** dst2 = nullptr);
   int dev_alloc(void** dst, size_t bytes);
+  size_t slot_bytes(const WeightSlot& s) const;
   int ensure_ctx_cache(int B, int Lctx);
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;

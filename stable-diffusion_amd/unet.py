@@ -161,6 +161,33 @@ class UNetModelHIP(nn.Module):
         self._packed_sig = self._signature()
         self._ctx_ref = None
 
+    # ---- packed-weight blob --------------------------------------------------------------------------
+    def save_packed(self, path):
+        """Write the library's packed fp16 weights (after pack()) to `path`: header + buffers, mmap-able."""
+        import numpy as np
+        if self._packed_sig is None or self._packed_sig != self._signature():
+            self.pack()
+        lib = self._handle.lib
+        n = int(lib.sdmi_unet_packed_bytes(self._handle.h))
+        buf = np.empty(n, dtype=np.uint8)
+        _lib.check(lib.sdmi_unet_export_packed(self._handle.h, buf.ctypes.data, n, _lib.stream_ptr()))
+        buf.tofile(path)
+        return n
+
+    def load_packed(self, path):
+        """Load a blob written by save_packed() / tools/pack_checkpoint.py straight into the library (no fp32 state_dict,
+        no repack).  The nn.Parameters of this module are left untouched (they are not used by forward())."""
+        import numpy as np
+        if not torch.cuda.is_available():
+            raise RuntimeError('UNetModelHIP runs on an MI355X only (no CPU fallback)')
+        blob = np.memmap(path, dtype=np.uint8, mode='r')
+        _lib.check(self._handle.lib.sdmi_unet_import_packed(self._handle.h, blob.ctypes.data, int(blob.shape[0]),
+                                                            _lib.stream_ptr()))
+        self._sentinels = None
+        self._packed_sig = self._signature()
+        self._ctx_ref = None
+        return self
+
     def _workspace(self, B, H, W, L, device):
         key = (B, H, W, L, str(device))
         if self._ws is None or self._ws[0] != key:

@@ -131,6 +131,33 @@ def test_batch_rows_are_independent(cfg_name, B, h, w):
           context=torch.zeros(9, 77, cfg.context_dim, device='cuda'))        # > 8 rows per call is refused, not truncated
 
 
+def test_packed_weight_blob_round_trip(tmp_path):
+    """SURVEY.md 8 f-4: save_packed() -> load_packed() into a fresh handle gives bit-identical eps without any state_dict;
+    blobs for another configuration, truncated blobs and non-blobs are refused."""
+    from stable_diffusion_amd import UNetModelHIP
+    from stable_diffusion_amd._lib import SdmiError
+    m, sd = _model('tiny', 0)
+    x, t, ctx = make_inputs(TINY, 2, 16, 16, seed=7)
+    ref = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    path = str(tmp_path / 'tiny.sdmi')
+    n = m.save_packed(path)
+    assert os.path.getsize(path) == n and n > 1e6
+    kw = TINY.ref_kwargs()
+    fresh = UNetModelHIP(**kw).cuda().load_packed(path)          # parameters stay zero: the blob is the only weight source
+    out = fresh(x.cuda(), t.cuda(), context=ctx.cuda())
+    assert torch.equal(out, ref)
+    other = UNetModelHIP(**dict(kw, num_res_blocks=kw['num_res_blocks'] + 1)).cuda()
+    with pytest.raises(SdmiError, match='different UNet configuration'):
+        other.load_packed(path)
+    bad = str(tmp_path / 'trunc.sdmi')
+    open(bad, 'wb').write(open(path, 'rb').read()[: n // 2])
+    with pytest.raises(SdmiError, match='truncated'):
+        UNetModelHIP(**kw).cuda().load_packed(bad)
+    open(bad, 'wb').write(b'x' * 4096)
+    with pytest.raises(SdmiError, match='not a libsdmi'):
+        UNetModelHIP(**kw).cuda().load_packed(bad)
+
+
 def test_refuses_cpu_and_bad_config():
     from stable_diffusion_amd import UNetModelHIP
     m, sd = _model('tiny', 0)
