@@ -405,6 +405,22 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
       }
     }
   } else {  // EPI_HEADS
+    if (p.splitk > 1) {   // split-K: raw partial tile to this split's slab; splitk_reduce_heads_kernel scatters the sum
+      float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 32 + l31;
+            if (n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+          }
+        }
+      return;
+    }
     // lane = output column (seg, head, dd); registers 4q..4q+3 = 4 consecutive rows (tokens)
     const bool vec4 = (p.ntok % 4 == 0) && (p.ntok_pad % 4 == 0);
 #pragma unroll
@@ -482,6 +498,38 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
   }
 }
 
+// the same reduction for the per-head scatter epilogue: quad (m, n..n+3) lies inside one head (dh % 4 == 0)
+__global__ void __launch_bounds__(256) splitk_reduce_heads_kernel(IGemmParams p, int nsplit) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int nq = p.N / 4;
+  if (idx >= (int64_t)p.M * nq) return;
+  const int m = (int)(idx / nq);
+  const int n = (int)(idx - (int64_t)m * nq) * 4;
+  const size_t slab_sz = (size_t)p.M * p.N;
+  const float* src = p.splitk_ws + (size_t)m * p.N + n;
+  f32x4 part[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0, 0, 0, 0};
+  f32x4 v = part[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s) v += part[s];
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  const int seg = n / p.segC;
+  const int c = n - seg * p.segC;
+  const int head = c / p.dh;
+  const int dd = c - head * p.dh;
+  const int b = m / p.ntok;
+  const int tok = m - b * p.ntok;
+  const size_t bh = (size_t)b * p.heads + head;
+  f16* dst = p.seg_dst[seg];
+  if (p.seg_kind[seg] == 0) {
+    *(f16x4*)(dst + (bh * p.ntok + tok) * p.dh + dd) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[(bh * p.dh + dd + j) * p.ntok_pad + tok] = (f16)v[j];
+  }
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
@@ -523,6 +571,13 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
 
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   SDMI_CHECK(nsplit >= 1 && nsplit <= 16 && p.N % 4 == 0 && p.splitk_ws, "splitk_reduce: bad arguments");
+  if (p.mode == EPI_HEADS) {
+    const int64_t total_h = (int64_t)p.M * (p.N / 4);
+    ProfScope psh("splitk_reduce", 0.0, (double)p.M * p.N * (4.0 * nsplit + 2.0), stream);
+    hipLaunchKernelGGL(splitk_reduce_heads_kernel, dim3((unsigned)((total_h + 255) / 256)), dim3(256), 0, stream, p, nsplit);
+    SDMI_HIP_OK(hipGetLastError());
+    return 0;
+  }
   const int64_t total = (int64_t)p.M * (p.N / 4);
   ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, nsplit);
@@ -577,8 +632,11 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   int splitk = p.splitk;
   const int nkt = p.K / BK;
   static const int env_split = env_int("SDMI_SPLITK", -1);     // 1 disables split-K everywhere
-  const bool can_split = p.mode == EPI_PLAIN && p.splitk_ws && p.N % 4 == 0 && p.ldo % 4 == 0 &&
-                         (p.residual == nullptr || p.ldr % 4 == 0);
+  const bool can_split_plain = p.mode == EPI_PLAIN && p.splitk_ws && p.N % 4 == 0 && p.ldo % 4 == 0 &&
+                               (p.residual == nullptr || p.ldr % 4 == 0);
+  // (the executors keep the head-scatter GEMMs unsplit: a same-box A/B showed split-K + reduce no faster there)
+  const bool can_split_heads = p.mode == EPI_HEADS && p.splitk_ws && p.dh % 4 == 0 && p.segC % 4 == 0;
+  const bool can_split = can_split_plain || can_split_heads;
   if (env_split >= 0 && splitk == 0) splitk = env_split;
   if (splitk <= 0) {  // auto: enough blocks to keep bytes in flight on all 256 CUs, >= 8 k-tiles per split
     splitk = 1;
@@ -593,7 +651,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     }
   }
   if (splitk > 1) {
-    SDMI_CHECK(can_split, "split-K needs plain mode, a slab workspace and N / ldo / ldr multiples of 4");
+    SDMI_CHECK(can_split, "split-K needs plain or head-scatter mode, a slab workspace and N / ldo / ldr multiples of 4");
     SDMI_CHECK((int64_t)splitk * p.M * p.N <= p.splitk_ws_floats, "split-K workspace too small");
   }
   switch (tile) {            // tile ids: see include/sdmi.h (sdmi_igemm_desc.tile)

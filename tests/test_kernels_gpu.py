@@ -202,6 +202,37 @@ def test_igemm_head_scatter(ntok, d, heads):
     assert float(vt[:, :, ntok:].abs().max()) == 0.0 if ntp != ntok else True
 
 
+@pytest.mark.parametrize('ntok,d,heads,Kd,splitk', [(256, 160, 8, 1280, 4), (77, 64, 12, 768, 3), (100, 40, 8, 1024, 0)])
+def test_igemm_head_scatter_splitk(ntok, d, heads, Kd, splitk):
+    """per-head scatter with split-K: slabs + splitk_reduce_heads_kernel (bias included, ragged token counts)."""
+    g = _g(8)
+    B = 2
+    C = heads * d
+    M = B * ntok
+    a = _rand16((M, Kd), g)
+    w = _rand16((3 * C, Kd), g, 1.0 / math.sqrt(Kd))
+    bias = torch.randn(3 * C, generator=g) * 0.1
+    y = (a.float() @ w.float().t() + bias).reshape(B, ntok, 3, heads, d)
+    ntp = (ntok + 7) // 8 * 8
+    outs = []
+    for rep in range(2):
+        q = torch.zeros((B * heads, ntok, d), dtype=torch.float16, device=DEV)
+        k = torch.zeros_like(q)
+        vt = torch.zeros((B * heads, d, ntp), dtype=torch.float16, device=DEV)
+        K.igemm(a.to(DEV), w.to(DEV).contiguous(), 3 * C, B, ntok, 1, ntok, 1, mode=2, bias=bias.to(DEV), splitk=splitk,
+                heads=dict(segs=[(q, 0), (k, 0), (vt, 1)], heads=heads, dh=d, ntok=ntok, ntok_pad=ntp, segC=C))
+        outs.append((q, k, vt))
+    torch.cuda.synchronize()
+    q, k, vt = outs[0]
+    qr = y[:, :, 0].permute(0, 2, 1, 3).reshape(B * heads, ntok, d)
+    kr = y[:, :, 1].permute(0, 2, 1, 3).reshape(B * heads, ntok, d)
+    vr = y[:, :, 2].permute(0, 2, 3, 1).reshape(B * heads, d, ntok)
+    assert K.report(f'heads splitk{splitk} q', q, qr, 6e-3) < 6e-3
+    assert K.report(f'heads splitk{splitk} k', k, kr, 6e-3) < 6e-3
+    assert K.report(f'heads splitk{splitk} vt', vt[:, :, :ntok], vr, 6e-3) < 6e-3
+    assert all(torch.equal(x, y_) for x, y_ in zip(outs[0], outs[1]))
+
+
 def test_igemm_sd_l0_conv_shape():
     """The dominant SD-v1 shape: 320->320 3x3 at 64x64, CFG batch 2."""
     g = _g(8)
