@@ -217,6 +217,15 @@ int DevStage::release(hipStream_t stream) {
 
 UNet::~UNet() {
   for (void* p : owned_) (void)hipFree(p);
+  auto drop_ctx = [](Layer& L) {            // cross-attention K / V^T caches (ensure_ctx_cache)
+    for (auto& T : L.tb) {
+      if (T.ck) (void)hipFree(T.ck);
+      if (T.cvt) (void)hipFree(T.cvt);
+    }
+  };
+  for (auto& blk : input_blocks_) for (auto& L : blk) drop_ctx(L);
+  for (auto& L : middle_) drop_ctx(L);
+  for (auto& blk : output_blocks_) for (auto& L : blk) drop_ctx(L);
 }
 
 int UNet::dev_alloc(void** dst, size_t bytes) {
