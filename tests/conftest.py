@@ -24,6 +24,14 @@ def pytest_configure(config):
     import torch
     # the GPU boxes expose 256 logical CPUs under a 16-CPU cgroup quota: torch's default thread count thrashes there
     torch.set_num_threads(min(32, _usable_cores()))
+    # a clean checkout has no libsdmi.so (built artefacts are git-ignored): build it once (hipcc cross-compiles without a
+    # GPU, ~1 min); a stale library is rebuilt too, so the tests never run against yesterday's kernels
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('sdmi_build', os.path.join(ROOT, 'stable-diffusion_amd', 'build.py'))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    if not b.is_current():
+        b.build(force=False, verbose=False)
 
 
 def pytest_collection_modifyitems(config, items):
