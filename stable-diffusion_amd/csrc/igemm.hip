@@ -615,7 +615,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   int tile = tune.tile >= 0 ? tune.tile : env_tile;
   static const int env_geglu = env_int("SDMI_TILE_GEGLU", 0);
   if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3 || tile == 6 || tile == 7)) tile = env_geglu;   // GEGLU pairs 32-col tiles inside a wave
-  // Tile / split-K choice, from the per-shape sweep of tools/bench_kernels.py on MI355X (profiles/kbench_r01.txt):
+  // Tile / split-K choice, from the per-shape sweep of tests/tools/bench_kernels.py on MI355X (profiles/kbench_r01.txt):
   // every shape of this UNet is bound by L2->LDS bytes in flight, so the many-block 64x64 tile wins except for
   // the few >= 25 GFLOP convs, where the 256x128 tile (fewest bytes per FLOP) is ~10 % faster.
   const double gflop = 2.0 * p.M * (double)p.N * p.K * 1e-9;

@@ -1,7 +1,7 @@
 """Micro-benchmark of every distinct GEMM / conv / attention shape of one SD-v1 UNet call (CFG batch 2) on the GPU,
 sweeping the igemm tile / staging / split-K knobs.  Run on the GPU box; prints a table and writes gpurun_out/kernels.json.
 
-    python tools/bench_kernels.py [--h 64] [--quick]
+    python tests/tools/bench_kernels.py [--h 64] [--quick]
 """
 import argparse
 import json
@@ -9,7 +9,7 @@ import math
 import os
 import sys
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import torch  # noqa: E402

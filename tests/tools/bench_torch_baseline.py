@@ -1,12 +1,12 @@
 """GPU baseline beside the CPU baseline (SURVEY.md 8c "On the GPU box"): the oracle's functional restatement of the
 reference UNet (same aten ops as the reference modules: conv2d / linear / einsum-bmm / softmax / group_norm / layer_norm
 / gelu) on PyTorch-ROCm, fp32 and fp16 autocast, CFG batch 2 at 64x64 -- next to libsdmi on the same box.
-    python tools/bench_torch_baseline.py"""
+    python tests/tools/bench_torch_baseline.py"""
 import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import torch  # noqa: E402
 

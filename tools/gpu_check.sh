@@ -11,7 +11,7 @@ for f in ${TEST_FILES:-test_kernels_gpu test_unet_gpu test_sampler_gpu}; do
   echo "== $f: $(grep -E 'passed|failed|error' gpurun_out/$f.log | tail -1) $(tail -1 gpurun_out/$f.log)"
 done
 if [ "${RUN_KBENCH:-0}" = "1" ]; then
-  timeout 900 python tools/bench_kernels.py ${KBENCH_ARGS} > gpurun_out/kbench.log 2>&1
+  timeout 900 python tests/tools/bench_kernels.py ${KBENCH_ARGS} > gpurun_out/kbench.log 2>&1
   echo "kbench exit $?"; tail -45 gpurun_out/kbench.log
 fi
 if [ "${RUN_BENCH:-1}" = "1" ]; then
