@@ -23,6 +23,8 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
+# the host driver only supports dmabuf IPC: RCCL needs this before HIP initialises (already exported on the GPU boxes)
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
