@@ -179,6 +179,38 @@ def cpu_baseline(n_unet_calls=2):
                       f'({t_vae:.2f} s), extrapolated to 51 calls + 1 decode = {s_per_image:.1f} s/image'}
 
 
+def timed_steps(step_fn, steps, warmup, world, rank, device):
+    """The driver's timing contract: `warmup` untimed steps, then exactly `steps` steps bracketed by a barrier + device
+    synchronize on both sides; returns (max-over-ranks seconds, last local latent, last image, last gathered latents).
+    `step_fn(step) -> (latent, image)`; every rank all_gathers its finished latent once per step (the path's only
+    collective).  Device-agnostic so tests/test_dist_gloo.py can run it with world_size 2 on the CPU."""
+    import contextlib
+    import io
+    from stable_diffusion_amd import dist as sd_dist
+    quiet = contextlib.redirect_stdout(io.StringIO())
+
+    def sync():
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        if device.type == 'cuda':
+            torch.cuda.synchronize()
+    with quiet:
+        for w in range(warmup):
+            step_fn(-1 - w)
+    sync()
+    t0 = time.perf_counter()
+    lat = img = allz = None
+    with quiet:
+        for s in range(steps):
+            lat, img = step_fn(s)
+            allz = sd_dist.gather_latents(lat, world, rank, world)     # 64 KiB per image
+    sync()
+    elapsed = sd_dist.max_over_ranks(time.perf_counter() - t0, device)
+    return elapsed, lat, img, allz
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -211,28 +243,12 @@ def main():
     guc = torch.Generator(device='cpu').manual_seed(2)
     uc = (0.1 * torch.randn(1, 77, 768, generator=guc)).to(device)
 
-    import io
-    import contextlib
-    quiet = contextlib.redirect_stdout(io.StringIO())
-    with quiet:
-        for w in range(args.warmup):
-            c, x_T = inputs(-1 - w)
-            one_image(sampler, vae, c, uc, x_T)
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    with quiet:
-        for s in range(args.steps):
-            c, x_T = inputs(s)
-            lat, img = one_image(sampler, vae, c, uc, x_T)
-            allz = sd_dist.gather_latents(lat, world, rank, world)     # the only collective: 64 KiB per image
-    torch.cuda.synchronize()
-    if world > 1:
-        torch.distributed.barrier()
-    torch.cuda.synchronize()
-    elapsed = sd_dist.max_over_ranks(time.perf_counter() - t0, device)
+    def inputs_for(step):
+        c, x_T = inputs(step)
+        return c, uc, x_T
+
+    elapsed, lat, img, allz = timed_steps(lambda step: one_image(sampler, vae, *inputs_for(step)), args.steps, args.warmup,
+                                          world, rank, device)
     assert torch.isfinite(img).all() and torch.isfinite(allz).all()
 
     out = None

@@ -54,3 +54,40 @@ def test_single_process_passthrough():
     assert sd_dist.gather_latents(x, 3, 0, 1) is x
     assert sd_dist.shard(['a', 'b', 'c'], 0, 1) == [(0, 'a'), (1, 'b'), (2, 'c')]
     assert sd_dist.shard(['a', 'b', 'c'], 1, 2) == [(1, 'b')]
+
+
+def _bench_worker(rank, world, port, q):
+    """bench.py's timed region (barrier-bracketed steps, one latent all_gather per step, max-over-ranks time) with a fake
+    per-step workload: rank 1 is slower, so the reported time must be rank 1's on both ranks."""
+    import time
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import bench
+    from stable_diffusion_amd import dist as sd_dist
+    r, w, _ = sd_dist.init_from_env(backend='gloo')
+    calls = []
+
+    def step(s):
+        calls.append(s)
+        time.sleep(0.05 * (1 + 3 * rank))
+        gidx = s * w + r                                   # global prompt index, as bench.py seeds its inputs
+        return torch.full((1, 4, 8, 8), float(gidx)), torch.zeros(1, 3, 8, 8)
+    elapsed, lat, img, allz = bench.timed_steps(step, 3, 2, w, r, torch.device('cpu'))
+    ok = calls == [-1, -2, 0, 1, 2] and allz.shape == (w, 4, 8, 8) and [float(allz[i].mean()) for i in range(w)] == [4.0, 5.0]
+    q.put((rank, bool(ok), elapsed))
+    dist.destroy_process_group()
+
+
+def test_bench_timed_region_world2():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res)
+    assert res[0][2] == res[1][2] and 0.55 <= res[0][2] < 2.0         # 3 steps x 0.2 s on the slow rank, seen by both
