@@ -248,3 +248,24 @@ def test_plugin_seam_against_the_real_reference():
     want['transformer.text_model.embeddings.position_ids'] = (1, 77)
     assert {k: tuple(v.shape) for k, v in mine.state_dict().items()} == want
     assert hasattr(mine, 'encode') and hasattr(mine, 'freeze')
+
+
+def test_committed_bench_line_has_the_contract_keys():
+    """profiles/bench_r01.json is the JSON line `python bench.py` printed on the MI355X: the driver's contract keys, the
+    roofline / cpu_baseline objects, and internally consistent numbers."""
+    import json
+    d = json.load(open(os.path.join(ROOT, 'profiles', 'bench_r01.json')))
+    for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+              'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert k in d, k
+    assert d['unit'] == 'images/s' and d['higher_is_better'] is True and d['scaling'] == 'weak' and d['n_gpus'] == 1
+    assert d['vs_baseline'] is None and d['data'] == 'synthetic' and 'workload' in d['config'] and 'model' not in d['config']
+    assert abs(d['value'] - d['n_gpus'] * 1000.0 / d['ms_per_step']) < 1e-6 * d['value'] + 1e-9
+    r = d['roofline']
+    for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'traffic'):
+        assert k in r, k
+    assert r['bound'] in ('hbm', 'mfma') and abs(r['frac'] - r['achieved'] / r['peak']) < 1e-9 and 0 < r['frac'] < 1
+    c = d['cpu_baseline']
+    for k in ('value', 'unit', 'cores', 'kind', 'sample'):
+        assert k in c, k
+    assert c['kind'] in ('port', 'reference') and c['unit'] == d['unit'] and d['value'] / c['value'] >= 8.0   # north_star: >= 8x
