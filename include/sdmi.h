@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 5
+#define SDMI_ABI_VERSION 6
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -181,8 +181,9 @@ typedef struct sdmi_igemm_desc {
   int32_t heads, dh, ntok, ntok_pad, segC;
   int32_t splitk;                       /* 1 none, 0 auto, >1 forced (plain mode; needs splitk_ws) */
   float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs [splitk][M][N] */
-  int32_t tile;                         /* -1 auto; 0 128x128, 1 128x64, 2 64x64, 3 256x128 (8 waves) -- double buffered;
-                                           4 128x64, 5 64x64, 6 256x128, 7 128x128 with a 3-stage LDS-DMA pipeline */
+  int32_t tile;                         /* -1 auto (tuning table); BMxBN/waves/LDS-DMA stages: 0 128x128/4/2, 1 128x64/4/2,
+                                           2 64x64/4/2, 3 256x128/8/2, 4 128x64/4/3, 5 64x64/4/3, 6 256x128/8/3, 7 128x128/4/3,
+                                           8 64x128/4/3, 9 128x128/8/3, 10 64x64/4/4, 11 128x256/8/2, 12 64x256/4/3, 13 256x64/4/3 */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
   int32_t asym_pad;                     /* 3x3 only: 0 = zero pad 1 on every side; 1 = pad right/bottom only, i.e.
                                            F.pad(x,(0,1,0,1)) + conv(padding=0) of the VAE Downsample (model.py:72-76) */
@@ -226,6 +227,15 @@ int sdmi_k_pointwise_nchw(const float* x, const float* w, const float* bias, flo
                           float in_scale, void* stream);
 int sdmi_k_softmax_rows(const float* S, void* P_f16, int rows, int cols, float scale, void* stream);
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst_f16, float* bdst, int N, int K, void* stream);
+/* In-situ tuning of the implicit-GEMM tile / split-K choice (no reference counterpart: the reference delegates to
+ * MIOpen / hipBLASLt heuristics).  begin -> for r in rounds: sdmi_tune_round(r), run the workloads -> end: every
+ * auto-configured GEMM launch between begin and end runs candidate (r mod #candidates) of its shape, timed with HIP
+ * events on its stream; end folds the timings into the table and writes it (path NULL = next to libsdmi.so, where it
+ * is loaded from at start-up).  sdmi_tune_dump: per-candidate timings of the last collection as text. */
+int sdmi_tune_begin(void);
+int sdmi_tune_round(int r);
+int sdmi_tune_end(const char* path, int* n_keys);
+int sdmi_tune_dump(char* buf, int buflen);
 /* per-launch timing of the library's kernels (HIP events on the launch stream): begin, run forwards, then end
  * writes a JSON array [{"name","launches","ms","flops","bytes"}] (algorithmic flops / bytes per kernel class) */
 int sdmi_profile_begin(void);

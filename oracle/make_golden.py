@@ -79,9 +79,19 @@ def main():
         ('sdv1_32x32', SD_V1, 0, 2, 32, 32, 77),
         ('sdv1_64x64', SD_V1, 0, 2, 64, 64, 77),
         ('sdv1_96x96', SD_V1, 0, 2, 96, 96, 77),     # BASELINE.json configs[3]: 768x768, 9216 tokens
+        # SURVEY 8c hygiene (4): t in {1, 481, 981} must reach a whole-UNet reference comparison -- the batch-2 cases above
+        # only see (981, 481); and txt2img's default n_samples = 3 is a CFG batch of 6 (scripts/txt2img.py:110-114)
+        ('sdv1_t1_741_16x16', SD_V1, 0, 2, 16, 16, 77, (1, 741)),
+        ('sdv1_b6_16x16', SD_V1, 0, 6, 16, 16, 77),          # t = (981, 481, 1, 741, 981, 481)
+        ('tiny_b6_16x16', TINY, 0, 6, 16, 16, 77),
+        ('tiny_b10_8x8', TINY, 0, 10, 8, 8, 77),             # > 8 rows: UNetModelHIP.forward chunks (n_samples = 5)
     ]
+    only = [a for a in sys.argv[1:] if not a.startswith('-')]
+    if only:
+        cases = [c for c in cases if c[0] in only]
     ref_models = {}
-    for name, cfg, wseed, b, h, w, L in cases:
+    for name, cfg, wseed, b, h, w, L, *rest in cases:
+        tsteps = rest[0] if rest else (981, 481, 1, 741)
         key = (cfg, wseed)
         if key not in ref_models:
             ref_models.clear()  # keep memory bounded
@@ -92,7 +102,7 @@ def main():
             print(f'[{name}] reference UNetModel loaded strict=True: {len(sd)} tensors, {n_params} params', flush=True)
             ref_models[key] = (m, sd)
         m, sd = ref_models[key]
-        x, t, ctx = make_inputs(cfg, b, h, w, seed=1, ctx_len=L)
+        x, t, ctx = make_inputs(cfg, b, h, w, seed=1, ctx_len=L, timesteps=tsteps)
         with torch.no_grad():
             eps_ref = m(x, t, context=ctx)
         taps = {}
@@ -107,6 +117,9 @@ def main():
                             t=t.numpy(), eps_absmax=float(eps_ref.abs().max()),
                             oracle_vs_reference=err)
     ref_models.clear()
+    if only:
+        print('golden fixtures written to', out_dir, '(subset:', only, ')')
+        return
 
     # ---- schedule constants (SURVEY a19 goldens) ------------------------------------------
     betas_ref = ref_util.make_beta_schedule('linear', 1000, linear_start=0.00085, linear_end=0.0120)

@@ -105,6 +105,10 @@ _SIGS = {
     'sdmi_k_pack_conv_out': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_split3': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_geglu': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
+    'sdmi_tune_begin': (C.c_int, []),
+    'sdmi_tune_round': (C.c_int, [C.c_int]),
+    'sdmi_tune_end': (C.c_int, [C.c_char_p, C.POINTER(C.c_int)]),
+    'sdmi_tune_dump': (C.c_int, [C.c_char_p, C.c_int]),
     'sdmi_profile_begin': (C.c_int, []),
     'sdmi_profile_end': (C.c_int, [C.c_char_p, C.c_int]),
     'sdmi_zero_page': (c_ptr, []),
@@ -129,7 +133,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 5:
+        if lib.sdmi_abi_version() != 6:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -313,6 +313,17 @@ int sdmi_k_pack_split3(const float* w, void* dst, int N, int K, void* stream) {
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst, float* bdst, int N, int K, void* stream) {
   return launch_pack_geglu(w, bias, (f16*)wdst, bdst, N, K, (hipStream_t)stream);
 }
+int sdmi_tune_begin(void) { return tune_begin(); }
+int sdmi_tune_round(int r) { return tune_round(r); }
+int sdmi_tune_end(const char* path, int* n_keys) { return tune_end(path, n_keys); }
+int sdmi_tune_dump(char* buf, int buflen) {
+  SDMI_CHECK(buf && buflen > 1, "null buffer");
+  std::string txt;
+  if (tune_dump(&txt)) return -1;
+  SDMI_CHECK((int)txt.size() + 1 <= buflen, "tune dump buffer too small");
+  memcpy(buf, txt.c_str(), txt.size() + 1);
+  return 0;
+}
 int sdmi_profile_begin(void) { return prof_begin(); }
 int sdmi_profile_end(char* buf, int buflen) {
   SDMI_CHECK(buf && buflen > 2, "null buffer");

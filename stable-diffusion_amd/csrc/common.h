@@ -88,15 +88,23 @@ struct IGemmParams {
   int splitk = 1;                                      // 1 none, 0 auto, >1 forced
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
-  int debug = 0;                                       // perf ablation only (SDMI_IGEMM_ABLATE): 1 skip k-loop loads, 2 skip MFMA work
+  // filled by the launcher: ceil(2^40 / (Hout*Wout)) and ceil(2^40 / Wout) for the kernel's division-free row split
+  unsigned long long magic_hw = 0, magic_w = 0;
 };
 
-struct IGemmTune {        // runtime knobs (tests sweep them; the executor picks by heuristic)
-  int tile = -1;          // -1 auto, 0: 128x128, 1: 128x64, 2: 64x64
+constexpr int SDMI_NUM_TILES = 14;   // tile ids 0 .. 13, see kTiles in igemm.hip and include/sdmi.h
+struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes the tuning table's choice)
+  int tile = -1;          // -1 auto (tuning table, then heuristic); else a tile id
   int dma = -1;           // -1 default, 0 register-staged loads, 1 global_load_lds
 };
 
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream);
+// in-situ tuning (igemm.hip): begin a collection run, select the candidate index for the following launches, end it
+// (folds the timings into the table and writes it to `path`, or next to libsdmi.so when NULL)
+int tune_begin();
+int tune_round(int r);
+int tune_end(const char* path, int* n_keys);
+int tune_dump(std::string* out);
 // out = sum_s slab[s] + bias + rowvec[batch] + residual (fixed order); uses M, N, Hout*Wout, splitk_ws, out_f32/out_f16
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
 

@@ -21,6 +21,13 @@
 //     GEGLU (value * gelu_erf(gate), weights pre-interleaved in 32-row groups); per-head scatter of
 //     q / k / v^T for the attention kernel; split-K via fp32 atomics onto a pre-initialised output.
 //   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles.
+#include <dlfcn.h>
+
+#include <map>
+#include <mutex>
+#include <tuple>
+#include <vector>
+
 #include "common.h"
 #include "prof.h"
 
@@ -50,24 +57,37 @@ __device__ __forceinline__ float gelu_erf(float x) {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {   // counted wait: the immediate must be a literal
-  static_assert(N == 0 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24, "add the literal");
+  static_assert(N >= 0 && N <= 30 && N % 2 == 0, "add the literal");
+#define SDMI_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-  else if constexpr (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  SDMI_VMCNT_CASE(2); SDMI_VMCNT_CASE(4); SDMI_VMCNT_CASE(6); SDMI_VMCNT_CASE(8); SDMI_VMCNT_CASE(10);
+  SDMI_VMCNT_CASE(12); SDMI_VMCNT_CASE(14); SDMI_VMCNT_CASE(16); SDMI_VMCNT_CASE(18); SDMI_VMCNT_CASE(20);
+  SDMI_VMCNT_CASE(22); SDMI_VMCNT_CASE(24); SDMI_VMCNT_CASE(26); SDMI_VMCNT_CASE(28); SDMI_VMCNT_CASE(30);
+#undef SDMI_VMCNT_CASE
+}
+
+// Kernel kinds: the gather of the implicit A matrix differs, so each is its own instantiation (no runtime branches and no
+// dead per-row state in the k-loop).
+enum : int { KIND_1X1 = 0, KIND_3X3 = 1, KIND_3X3_UP = 2 };
+
+// floor(m / d) for 0 <= m, m * d < 2^40, with magic = ceil(2^40 / d) (host computed): the per-row (batch, y, x) split of
+// the prologue without the ~40-instruction integer division sequences
+__device__ __forceinline__ int fast_div(int m, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
 }
 
 // NS = LDS pipeline depth.  DMA path: NS-1 k-tiles are in flight across the (raw) barrier, retired by a counted
 // s_waitcnt vmcnt(N); the global->LDS latency (~1 us under load) is several k-tiles of MFMA work, so NS = 2 leaves
 // every block waiting on its single outstanding tile.
-template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA, int NS, bool UP>
+template <int BM, int BN, int WARPS_M, int WARPS_N, bool DMA, int NS, int KIND>
 __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGemmParams p, const int tiles_m,
                                                                        const int tiles_n, const int kt_per_split) {
   static_assert(DMA || NS == 2, "the register-staged path is double buffered");
+  // The body uses gfx950-only types / builtins (buffer descriptors, LDS-DMA); hipcc's host pass only needs the launch
+  // stub, and silently drops the stub of an instantiation whose body it cannot type-check -- so the body is device-only.
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr bool UP = KIND == KIND_3X3_UP;
+  constexpr bool K3 = KIND != KIND_1X1;
   constexpr int NT = WARPS_M * WARPS_N * 64;
   constexpr int RPP = NT / 8;  // rows per load pass (8 chunks of 16 B per 128-B row)
   constexpr int A_PASSES = BM / RPP;
@@ -105,48 +125,49 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   // ---- per-row gather metadata (computed once; the k-loop only adds wave-uniform offsets) -----------------
   // Row m of the implicit A matrix is output pixel (b, oy, ox).  Tap (ky, kx) of a 3x3 conv reads input pixel
-  // (oy*stride + ky - 1, ox*stride + kx - 1): an offset that is affine in the tap, so per row we keep the element
-  // offset of the centre tap and a 9-bit mask of the taps that fall inside the image.  (UP: nearest-x2 upsampled
+  // (oy*stride + ky - pad, ox*stride + kx - pad): an offset that is affine in the tap, so per row we keep the byte
+  // offset of tap (pad, pad) and a 9-bit mask of the taps that fall inside the image.  (UP: nearest-x2 upsampled
   // input -- the source pixel is ((oy+ky-1)>>1, (ox+kx-1)>>1), not affine, so the three row / column offsets
-  // are tabulated per row instead.)
+  // are tabulated per row instead.)  Rows past M (and weight rows past N) are CLAMPED to the last valid row: they
+  // compute a copy of it that the epilogue never stores, which keeps every load unconditional and in bounds.
   const int HWout = p.Hout * p.Wout;
-  const int Cin = p.c0 + p.c1 + p.c2;
-  const bool k3 = p.ksize == 3;
-  const int pad = k3 ? p.pad : 0;                   // 1, or 0 for the VAE encoder's (0,1,0,1)-padded stride-2 conv
-  const int ntap = p.ksize * p.ksize;
+  const int pad = K3 ? p.pad : 0;                   // 1, or 0 for the VAE encoder's (0,1,0,1)-padded stride-2 conv
+  constexpr int ntap = K3 ? 9 : 1;
   const int ld = p.lda0;                            // all sources share the row pitch (checked by the launcher)
-  int a_off[A_PASSES]; unsigned a_mask[A_PASSES];
+  int a_off[A_PASSES];                              // byte offsets (< 2^31, checked by the launcher)
+  unsigned a_mask[K3 ? A_PASSES : 1];
   int a_ro[UP ? A_PASSES : 1][3], a_co[UP ? A_PASSES : 1][3];
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
-    const int m = m0 + i * RPP + lrow;
-    a_off[i] = 0; a_mask[i] = 0;
-    if (m < p.M) {
-      const int b = m / HWout;
-      const int rem = m - b * HWout;
-      const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-      const int pb = b * p.Hin * p.Win;
-      if constexpr (UP) {
-        const int Hv = 2 * p.Hin, Wv = 2 * p.Win;
-        unsigned mk = 0;
+    const int m = min(m0 + i * RPP + lrow, p.M - 1);
+    const int b = fast_div(m, p.magic_hw);
+    const int rem = m - b * HWout;
+    const int oy = fast_div(rem, p.magic_w), ox = rem - oy * p.Wout;
+    const int pb = b * p.Hin * p.Win;
+    if constexpr (UP) {
+      const int Hv = 2 * p.Hin, Wv = 2 * p.Win;
+      unsigned mk = 0;
 #pragma unroll
-        for (int d = 0; d < 3; ++d) {
-          const int iy = oy + d - 1, ix = ox + d - 1;
-          a_ro[i][d] = (pb + (max(iy, 0) >> 1) * p.Win) * ld;
-          a_co[i][d] = (max(ix, 0) >> 1) * ld + gch * 8;
-        }
+      for (int d = 0; d < 3; ++d) {
+        const int iy = oy + d - 1, ix = ox + d - 1;
+        a_ro[i][d] = (pb + (max(iy, 0) >> 1) * p.Win) * ld * 2;
+        a_co[i][d] = ((max(ix, 0) >> 1) * ld + gch * 8) * 2;
+      }
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
+        if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) mk |= 1u << t;
+      }
+      a_mask[i] = mk;
+      a_off[i] = 0;
+    } else {
+      const int cy = oy * p.stride, cx = ox * p.stride;          // tap (pad, pad)
+      a_off[i] = ((pb + cy * p.Win + cx) * ld + gch * 8) * 2;
+      if constexpr (K3) {
+        unsigned mk = 0;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          const int iy = oy + t / 3 - 1, ix = ox + t % 3 - 1;
-          if (iy >= 0 && iy < Hv && ix >= 0 && ix < Wv) mk |= 1u << t;
-        }
-        a_mask[i] = mk;
-      } else {
-        const int cy = oy * p.stride, cx = ox * p.stride;          // centre tap
-        a_off[i] = (pb + cy * p.Win + cx) * ld + gch * 8;
-        unsigned mk = 0;
-        for (int t = 0; t < ntap; ++t) {
-          const int iy = cy + (k3 ? t / 3 - pad : 0), ix = cx + (k3 ? t % 3 - pad : 0);
+          const int iy = cy + t / 3 - pad, ix = cx + t % 3 - pad;
           if (iy >= 0 && iy < p.Hin && ix >= 0 && ix < p.Win) mk |= 1u << t;
         }
         a_mask[i] = mk;
@@ -156,61 +177,88 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   int b_off[B_PASSES];
 #pragma unroll
   for (int i = 0; i < B_PASSES; ++i) {
-    const int n = n0 + i * RPP + lrow;
-    b_off[i] = (n < p.N) ? (n * p.K + gch * 8) : -1;
+    const int n = min(n0 + i * RPP + lrow, p.N - 1);
+    b_off[i] = (n * p.K + gch * 8) * 2;
   }
 
   f16x8 regA[DMA ? 1 : A_PASSES], regB[DMA ? 1 : B_PASSES];
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);     // provably scalar -> LDS-DMA bases stay in SGPRs
 
-  // load cursor (wave-uniform): next k-tile to issue, its tap and first channel
+  // load cursor (wave-uniform): next k-tile to issue, its tap and first channel.  It stops on the last k-tile of this
+  // split: the NS - 1 surplus issues at the end of the pipeline reload that tile (in bounds, never consumed).
   int ld_kt = kt_begin;
   // K order is chunk-major: k-tile kt = (64-channel chunk, tap), tap fastest (see pack_conv_kernel)
-  int ld_tap = kt_begin % ntap;
+  int ld_tap = K3 ? kt_begin % ntap : 0;
   int ld_cin0 = (kt_begin / ntap) * BK;
-  int ld_ky = k3 ? ld_tap / 3 : 0, ld_kx = k3 ? ld_tap - 3 * (ld_tap / 3) : 0;
+  int ld_ky = K3 ? ld_tap / 3 : 0, ld_kx = K3 ? ld_tap - 3 * (ld_tap / 3) : 0;
 
+  // Operands are addressed through buffer descriptors (MUBUF): address = base + per-lane voffset + scalar soffset, so a
+  // pass costs no 64-bit VALU address arithmetic, and an out-of-image tap is a lane whose voffset is beyond num_records:
+  // the load returns zeros (also into LDS), no zero page and no pointer select.  MUBUF LDS-DMA also keeps the compiler's
+  // LDS wait counts exact: beside a FLAT-encoded global_load_lds every ds_read wait degrades to lgkmcnt(0) (round-1 ISA).
+  // The A base is moved back by the offset of tap (0, 0) relative to tap (pad, pad), so every tap's soffset is >= 0.
+  // Everything the k-loop touches lives in registers (no IGemmParams re-reads: those are scalar memory loads).
+  constexpr int OOB = (int)0x80000000;              // >= num_records of every descriptor below
+  const long long a_shift = (K3 && !UP) ? (long long)(pad * p.Win + pad) * ld * 2 : 0;
+  const char* const srcA0 = (const char*)p.a0 - a_shift; const char* const srcA1 = (const char*)p.a1 - a_shift;
+  const char* const srcA2 = (const char*)p.a2 - a_shift;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, OOB, 0x00020000);
+  const int pc0 = p.c0, pc01 = p.c0 + p.c1, pWin = p.Win;
+
+  // the scalar part of one k-tile's addresses, captured when the tile is scheduled; the per-pass issues may come later
+  struct TileCursor { __amdgpu_buffer_rsrc_t rsrc_a; int a_soff, b_soff; unsigned tapbit; int ky, kx; unsigned lds; };
+  auto next_tile = [&](int stage) {
+    TileCursor c;
+    const char* src; int coff;
+    if (ld_cin0 < pc0) { src = srcA0; coff = ld_cin0; }
+    else if (ld_cin0 < pc01) { src = srcA1; coff = ld_cin0 - pc0; }
+    else { src = srcA2; coff = ld_cin0 - pc01; }
+    c.rsrc_a = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, OOB, 0x00020000);
+    c.a_soff = ((K3 && !UP) ? (ld_ky * pWin + ld_kx) * ld + coff : coff) * 2;
+    c.b_soff = ld_kt * (BK * 2);
+    c.tapbit = 1u << ld_tap; c.ky = ld_ky; c.kx = ld_kx;
+    c.lds = stage * STAGE_BYTES;
+    if (ld_kt + 1 < kt_end) {      // advance (wave-uniform)
+      ++ld_kt;
+      if constexpr (K3) {
+        ++ld_tap;
+        if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
+        if (ld_tap == ntap) { ld_tap = 0; ld_ky = 0; ld_kx = 0; ld_cin0 += BK; }
+      } else {
+        ld_cin0 += BK;
+      }
+    }
+    return c;
+  };
+  // per-lane byte offset of activation pass i for tile c (OOB = this tap is outside the image: reads as zeros)
+  auto a_voff = [&](const TileCursor& c, int i) -> int {
+    int v;
+    if constexpr (UP) v = a_ro[i][c.ky] + a_co[i][c.kx];
+    else v = a_off[i];
+    if constexpr (K3) v = (a_mask[i] & c.tapbit) ? v : OOB;
+    return v;
+  };
+  auto issue_piece = [&](const TileCursor& c, int q) {     // LDS-DMA: wave-uniform LDS base + lane * 16
+    const unsigned row0 = (q < A_PASSES ? q * RPP : BM + (q - A_PASSES) * RPP) + wave_u * 8;
+    auto dst = (__attribute__((address_space(3))) void*)(smem + c.lds + row0 * 128);
+    if (q < A_PASSES) __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsrc_a, dst, 16, a_voff(c, q), c.a_soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q - A_PASSES], c.b_soff, 0, 0);
+  };
   auto issue_loads = [&](int stage) {
-    const bool live = ld_kt < kt_end;             // past the end (NS > 2): dummy loads from the zero page
-    const f16* src; int coff;
-    if (ld_cin0 < p.c0) { src = p.a0; coff = ld_cin0; }
-    else if (ld_cin0 < p.c0 + p.c1) { src = p.a1; coff = ld_cin0 - p.c0; }
-    else { src = p.a2; coff = ld_cin0 - p.c0 - p.c1; }
-    const int tapoff = ((ld_ky - pad) * p.Win + (ld_kx - pad)) * ld + coff;     // scalar
-    const unsigned tapbit = live ? (1u << ld_tap) : 0u;
-    unsigned char* As = smem + stage * STAGE_BYTES;
-    unsigned char* Bs = As + BM * 128;
+    const TileCursor c = next_tile(stage);
 #pragma unroll
-    for (int i = 0; i < A_PASSES; ++i) {
-      int off;
-      if constexpr (UP) off = a_ro[i][ld_ky] + a_co[i][ld_kx] + coff;
-      else off = a_off[i] + tapoff;
-      const f16* g = (a_mask[i] & tapbit) ? (src + off) : p.zero_page;
+    for (int q = 0; q < A_PASSES + B_PASSES; ++q) {
       if constexpr (DMA) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(As + (i * RPP + wave_u * 8) * 128),
-                                         16, 0, 0);
+        issue_piece(c, q);
       } else {
-        regA[i] = *(const f16x8*)g;
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        i32x4 v;
+        if (q < A_PASSES) v = __builtin_amdgcn_raw_buffer_load_b128(c.rsrc_a, a_voff(c, q), c.a_soff, 0);
+        else v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_w, b_off[q - A_PASSES], c.b_soff, 0);
+        if (q < A_PASSES) regA[q] = __builtin_bit_cast(f16x8, v);
+        else regB[q - A_PASSES] = __builtin_bit_cast(f16x8, v);
       }
     }
-    const f16* wk = p.w + ld_kt * BK;
-#pragma unroll
-    for (int i = 0; i < B_PASSES; ++i) {
-      const f16* g = (live && b_off[i] >= 0) ? (wk + b_off[i]) : p.zero_page;
-      if constexpr (DMA) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                         (__attribute__((address_space(3))) void*)(Bs + (i * RPP + wave_u * 8) * 128),
-                                         16, 0, 0);
-      } else {
-        regB[i] = *(const f16x8*)g;
-      }
-    }
-    // advance the cursor
-    ++ld_kt;
-    ++ld_tap;
-    if (++ld_kx == 3) { ld_kx = 0; ++ld_ky; }
-    if (ld_tap == ntap) { ld_tap = 0; ld_ky = 0; ld_kx = 0; ld_cin0 += BK; }
   };
   auto commit_regs = [&](int stage) {   // register-staged path: write the prefetched tile into LDS
     if constexpr (!DMA) {
@@ -235,35 +283,76 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  auto compute = [&](int stage) {
-    const unsigned char* As = smem + stage * STAGE_BYTES + (wm * WTM + l31) * 128;
-    const unsigned char* Bs = smem + stage * STAGE_BYTES + BM * 128 + (wn * WTN + l31) * 128;
+  // fragment reads of k-step ks (16 halves of K) of one stage: TM + TN ds_read_b128
+  const int a_lds = (wm * WTM + l31) * 128, b_lds = BM * 128 + (wn * WTN + l31) * 128;
+  auto read_frags = [&](int stage, int ks, f16x8 (&a)[TM], f16x8 (&b)[TN]) {
+    const unsigned char* st = smem + stage * STAGE_BYTES + (((ks * 2 + lg) ^ rsw) << 4);
 #pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      const int coff = (((ks * 2 + lg) ^ rsw) << 4);
-      f16x8 a[TM], b[TN];
+    for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(st + a_lds + i * 32 * 128);
 #pragma unroll
-      for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(As + i * 32 * 128 + coff);
+    for (int j = 0; j < TN; ++j) b[j] = *(const f16x8*)(st + b_lds + j * 32 * 128);
+  };
+  auto mfma_step = [&](const f16x8 (&a)[TM], const f16x8 (&b)[TN]) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) b[j] = *(const f16x8*)(Bs + j * 32 * 128 + coff);
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
-    }
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
   if constexpr (DMA) {
+    // Software pipeline (one raw s_barrier per k-tile, NS - 1 LDS-DMA tiles in flight across it):
+    //   * fragments are double buffered in registers: the ds_reads of k-step s + 1 are issued before the MFMAs of
+    //     k-step s, so the LDS latency sits under TM * TN MFMAs instead of in front of them (round 1 read, waited,
+    //     multiplied -- the compiler reused one fragment register set);
+    //   * the barrier that publishes tile t + 1 is taken BEFORE the last k-step of tile t and the first fragments of
+    //     tile t + 1 are read right behind it, under the cover of that last k-step's MFMAs;
+    //   * the LDS-DMA issues of tile t + NS - 1 (address VALU + one instruction per pass) are spread over the first
+    //     KS - 1 k-steps, in the shadow of the MFMAs, instead of in one block in front of them;
+    //   * stage (t - 1) % NS is refilled during iteration t: every wave finished (lgkmcnt(0)) all reads of tile t - 1
+    //     before it entered the barrier of iteration t - 1.
     constexpr int LPT = A_PASSES + B_PASSES;       // DMA instructions per thread per k-tile
+    constexpr int KS = BK / 16;
+    // pipeline unit = G k-steps: at least 4 MFMAs (128 cycles) of cover for the unit's TM + TN fragment reads
+    constexpr int G = (TM * TN >= 4) ? 1 : 2;
+    constexpr int U = KS / G;                      // units per k-tile (4 or 2)
+    constexpr int PPU = (LPT + U - 2) / (U - 1);   // DMA pieces issued in each of the first U - 1 units
+    constexpr int MPU = G * TM * TN;               // MFMAs per unit
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_loads(s);
+    wait_vmcnt<LPT*(NS - 2)>();
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    f16x8 fa[2][G][TM], fb[2][G][TN];
+#pragma unroll
+    for (int g = 0; g < G; ++g) read_frags(0, g, fa[0][g], fb[0][g]);
     int cur = 0, nxt = NS - 1;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-      wait_vmcnt<LPT*(NS - 2)>();                  // this wave's share of tile kt has landed
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody's; stage nxt is free again
-      if (!(p.debug & 1)) issue_loads(nxt);
-      if (!(p.debug & 2)) compute(cur);
-      cur = (cur + 1 == NS) ? 0 : cur + 1;
+      const TileCursor c = next_tile(nxt);
+      const int cur1 = (cur + 1 == NS) ? 0 : cur + 1;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (u + 1 < U) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) read_frags(cur, (u + 1) * G + g, fa[(u + 1) & 1][g], fb[(u + 1) & 1][g]);
+#pragma unroll
+          for (int q = u * PPU; q < (u + 1) * PPU && q < LPT; ++q) issue_piece(c, q);
+        } else {
+          wait_vmcnt<LPT*(NS - 2)>();               // this wave's share of tile kt + 1 has landed
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... and everybody's; tile kt is fully read
+#pragma unroll
+          for (int g = 0; g < G; ++g) read_frags(cur1, g, fa[0][g], fb[0][g]);
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) mfma_step(fa[u & 1][g], fb[u & 1][g]);
+        // pin the issue order of this unit: all fragment reads of the NEXT unit first (they land under this unit's
+        // MFMAs), then MFMAs with one LDS-DMA issue in each gap (masks: 0x100 DS read, 0x008 MFMA, 0x010 VMEM)
+        __builtin_amdgcn_sched_group_barrier(0x100, G * (TM + TN), 0);
+#pragma unroll
+        for (int e = 0; e < MPU; ++e) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (u + 1 < U && e < PPU && u * PPU + e < LPT) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+      }
+      cur = cur1;
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();
@@ -275,7 +364,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
       __syncthreads();
       const bool more = (kt + 1 < kt_end);
       if (more) issue_loads(cur ^ 1);
-      compute(cur);
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        f16x8 a[TM], b[TN];
+        read_frags(cur, ks, a, b);
+        mfma_step(a, b);
+      }
       if (more) commit_regs(cur ^ 1);
     }
   }
@@ -468,6 +562,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
         }
     }
   }
+#endif  // __HIP_DEVICE_COMPILE__
 }
 
 // out = sum_s slab[s] + bias + rowvec[batch] + residual   (fixed summation order -> deterministic)
@@ -530,6 +625,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_heads_kernel(IGemmParams p,
   }
 }
 
+static unsigned long long div_magic(int d) {      // ceil(2^40 / d), see fast_div
+  const unsigned long long one = 1ull << 40;
+  return (one + (unsigned long long)d - 1) / (unsigned long long)d;
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
@@ -538,11 +638,12 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int nsplit = cdiv(nkt, kt_per_split);
   IGemmParams q = p;
   q.splitk = nsplit;
-  static const int ablate = env_int("SDMI_IGEMM_ABLATE", 0);
-  q.debug = ablate;
+  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_w = div_magic(p.Wout);
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
   static const int by_shape = env_int("SDMI_PROF_SHAPES", 0);
-  std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "s" + std::to_string(NS);
+  std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "w" +
+                      std::to_string(WARPS_M * WARPS_N) + "s" + std::to_string(NS);
   if (by_shape && prof_enabled())
     pname += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + "_k" +
              std::to_string(p.ksize) + "_m" + std::to_string(p.mode) + "_s" + std::to_string(nsplit);
@@ -553,13 +654,18 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
                src_pix * (p.c0 + p.c1) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * n_out * out_b +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream);
-  if (p.up) {
-    if (dma) hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, true>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
-    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, true>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
-  } else {
-    if (dma) hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, false>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
-    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, false>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
-  }
+  const int kind = p.ksize == 1 ? KIND_1X1 : (p.up ? KIND_3X3_UP : KIND_3X3);
+#define SDMI_LAUNCH_KIND(K_)                                                                                        \
+  do {                                                                                                              \
+    if (dma) hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, K_>), grid, block, 0, stream, q,   \
+                                tiles_m, tiles_n, kt_per_split);                                                    \
+    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, K_>), grid, block, 0, stream, q,       \
+                            tiles_m, tiles_n, kt_per_split);                                                        \
+  } while (0)
+  if (kind == KIND_1X1) SDMI_LAUNCH_KIND(KIND_1X1);
+  else if (kind == KIND_3X3) SDMI_LAUNCH_KIND(KIND_3X3);
+  else SDMI_LAUNCH_KIND(KIND_3X3_UP);
+#undef SDMI_LAUNCH_KIND
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);     // (+ the LayerNorm launch when q.ln_out)
@@ -587,6 +693,206 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   return 0;
 }
 
+// ---- tile table ------------------------------------------------------------------------------------------------------
+// id: BM x BN, waves (M x N), per-wave MFMA tiles TM x TN, LDS-DMA stages.  TN even is required by the GEGLU epilogue.
+struct TileCfg { int bm, bn, wm, wn, ns; };
+static const TileCfg kTiles[SDMI_NUM_TILES] = {
+    {128, 128, 2, 2, 2},   //  0  2x2 tiles per wave, 64 KB  (2 blocks / CU)
+    {128, 64, 2, 2, 2},    //  1  2x1
+    {64, 64, 2, 2, 2},     //  2  1x1
+    {256, 128, 4, 2, 2},   //  3  8 waves, 2x2, 96 KB
+    {128, 64, 2, 2, 3},    //  4  2x1, 72 KB
+    {64, 64, 2, 2, 3},     //  5  1x1, 48 KB (3 blocks / CU)
+    {256, 128, 4, 2, 3},   //  6  8 waves, 2x2, 144 KB
+    {128, 128, 2, 2, 3},   //  7  2x2, 96 KB
+    {64, 128, 2, 2, 3},    //  8  1x2, 72 KB
+    {128, 128, 4, 2, 3},   //  9  8 waves, 1x2, 96 KB
+    {64, 64, 2, 2, 4},     // 10  1x1, 64 KB
+    {128, 256, 2, 4, 2},   // 11  8 waves, 2x2, 96 KB
+    {64, 256, 1, 4, 3},    // 12  4 waves, 2x2, 120 KB (small M, wide N: one A tile shared by the 4 waves)
+    {256, 64, 4, 1, 3},    // 13  4 waves, 2x2, 120 KB (large M, N = 5 x 64)
+};
+static inline bool tile_tn_even(int t) { return (kTiles[t].bn / kTiles[t].wn / 32) % 2 == 0; }
+
+static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
+  switch (tile) {            // tile ids: see include/sdmi.h (sdmi_igemm_desc.tile)
+    case 0: return launch_cfg<128, 128, 2, 2, 2>(p, dma, splitk, stream);
+    case 1: return launch_cfg<128, 64, 2, 2, 2>(p, dma, splitk, stream);
+    case 2: return launch_cfg<64, 64, 2, 2, 2>(p, dma, splitk, stream);
+    case 3: return launch_cfg<256, 128, 4, 2, 2>(p, dma, splitk, stream);
+    case 4: return launch_cfg<128, 64, 2, 2, 3>(p, dma, splitk, stream);
+    case 5: return launch_cfg<64, 64, 2, 2, 3>(p, dma, splitk, stream);
+    case 6: return launch_cfg<256, 128, 4, 2, 3>(p, dma, splitk, stream);
+    case 7: return launch_cfg<128, 128, 2, 2, 3>(p, dma, splitk, stream);
+    case 8: return launch_cfg<64, 128, 2, 2, 3>(p, dma, splitk, stream);
+    case 9: return launch_cfg<128, 128, 4, 2, 3>(p, dma, splitk, stream);
+    case 10: return launch_cfg<64, 64, 2, 2, 4>(p, dma, splitk, stream);
+    case 11: return launch_cfg<128, 256, 2, 4, 2>(p, dma, splitk, stream);
+    case 12: return launch_cfg<64, 256, 1, 4, 3>(p, dma, splitk, stream);
+    case 13: return launch_cfg<256, 64, 4, 1, 3>(p, dma, splitk, stream);
+    default: return fail("unknown igemm tile id");
+  }
+}
+
+// ---- per-shape tuning table ---------------------------------------------------------------------------------------
+// Tile shape and split-K of every auto-configured GEMM come from a table keyed by the GEMM's shape, measured ON the
+// MI355X in situ: during a collection run (sdmi_tune_begin / _round / _end, tools/tune.py) every launch site of a real
+// UNet / first-stage / text-encoder call runs candidate (round mod #candidates) of its shape, timed with HIP events on
+// the launch stream -- so each candidate sees the cache state of the real call (weights cold in HBM, activations warm
+// from the producing kernel), which a stand-alone micro-benchmark of one shape does not.  The table is a text file next
+// to libsdmi.so (stable-diffusion_amd/tune_gfx950.txt, committed): the choice is fixed, so results stay bit-reproducible.
+struct TuneKey {
+  int M, N, K, ksize, stride, up, mode, splitk_req;
+  bool operator<(const TuneKey& o) const {
+    return std::tie(M, N, K, ksize, stride, up, mode, splitk_req) <
+           std::tie(o.M, o.N, o.K, o.ksize, o.stride, o.up, o.mode, o.splitk_req);
+  }
+};
+struct TuneChoice { int tile, splitk; double us; };
+struct TuneRec { TuneKey key; int cand; hipEvent_t e0, e1; };
+
+class Tuner {
+ public:
+  std::mutex mu;
+  std::map<TuneKey, TuneChoice> table;
+  bool loaded = false, collecting = false;
+  int round = 0;
+  std::vector<TuneRec> recs;
+  std::map<TuneKey, std::vector<std::pair<TuneChoice, std::pair<double, int>>>> stats;   // per candidate: (sum us, n)
+  std::vector<hipEvent_t> pool;
+
+  static std::string default_path() {
+    if (const char* e = getenv("SDMI_TUNE_FILE")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&Tuner::default_path, &info) && info.dli_fname) {
+      std::string so = info.dli_fname;
+      const size_t k = so.find_last_of('/');
+      return (k == std::string::npos ? std::string(".") : so.substr(0, k)) + "/tune_gfx950.txt";
+    }
+    return "tune_gfx950.txt";
+  }
+  void load_file(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "r");
+    if (!f) return;
+    char line[256];
+    while (fgets(line, sizeof line, f)) {
+      if (line[0] == '#') continue;
+      TuneKey k; TuneChoice c; c.us = 0;
+      if (sscanf(line, "%d %d %d %d %d %d %d %d %d %d %lf", &k.M, &k.N, &k.K, &k.ksize, &k.stride, &k.up, &k.mode,
+                 &k.splitk_req, &c.tile, &c.splitk, &c.us) >= 10 && c.tile >= 0 && c.tile < SDMI_NUM_TILES && c.splitk >= 1 &&
+          c.splitk <= 16)
+        table[k] = c;
+    }
+    fclose(f);
+  }
+  void ensure_loaded() {
+    if (loaded) return;
+    loaded = true;
+    if (env_int("SDMI_TUNE_DISABLE", 0)) return;
+    load_file(default_path());
+  }
+  hipEvent_t ev() {
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+  }
+};
+static Tuner g_tuner;
+
+// candidate (tile, split-K) pairs of a shape, in a fixed order (the collection run indexes them by round)
+static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_split) {
+  std::vector<TuneChoice> out;
+  const int nkt = p.K / BK;
+  static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  for (int t = 0; t < SDMI_NUM_TILES; ++t) {
+    const TileCfg& c = kTiles[t];
+    if (c.ns == 2 && t != 0 && t != 3 && t != 11) continue;           // the 2-stage twins of 3-stage tiles are never faster
+    if (p.mode == EPI_GEGLU && !tile_tn_even(t)) continue;
+    const long blocks = (long)cdiv(p.M, c.bm) * cdiv(p.N, c.bn);
+    if ((long)c.bm > 2L * p.M && c.bm > 64) continue;                  // tile mostly padding
+    if ((long)c.bn > 2L * p.N && c.bn > 64) continue;
+    for (int sk : splits) {
+      if (sk > 1) {
+        if (p.splitk != 0 || !can_split) break;                        // caller pinned the split
+        if (nkt / sk < 4) break;                                       // >= 4 k-tiles per split
+        if (blocks * (sk / 2 + 1) > 1536) break;                       // already plenty of blocks one step earlier
+        if ((int64_t)sk * p.M * p.N > p.splitk_ws_floats) break;
+      }
+      if (blocks * sk < 48 && sk < 16 && nkt / (sk * 2) >= 4 && can_split && p.splitk == 0) continue;   // hopelessly few blocks
+      out.push_back({t, p.splitk > 1 ? p.splitk : sk, 0.0});
+      if (p.splitk != 0) break;
+    }
+  }
+  if (out.empty()) out.push_back({5, p.splitk > 0 ? p.splitk : 1, 0.0});
+  return out;
+}
+
+int tune_begin() {
+  std::lock_guard<std::mutex> lk(g_tuner.mu);
+  g_tuner.ensure_loaded();
+  g_tuner.collecting = true; g_tuner.round = 0;
+  g_tuner.recs.clear(); g_tuner.stats.clear();
+  return 0;
+}
+int tune_round(int r) {
+  std::lock_guard<std::mutex> lk(g_tuner.mu);
+  g_tuner.round = r;
+  return 0;
+}
+// fold the finished event pairs into the statistics (call with the device idle, e.g. after a stream synchronize)
+static int tune_drain() {
+  for (auto& r : g_tuner.recs) {
+    float ms = 0.f;
+    SDMI_HIP_OK(hipEventSynchronize(r.e1));
+    SDMI_HIP_OK(hipEventElapsedTime(&ms, r.e0, r.e1));
+    auto& v = g_tuner.stats[r.key];
+    if ((int)v.size() > r.cand) { v[r.cand].second.first += ms * 1e3; v[r.cand].second.second += 1; }
+    g_tuner.pool.push_back(r.e0); g_tuner.pool.push_back(r.e1);
+  }
+  g_tuner.recs.clear();
+  return 0;
+}
+int tune_end(const char* path, int* n_keys) {
+  std::lock_guard<std::mutex> lk(g_tuner.mu);
+  if (!g_tuner.collecting) return fail("sdmi_tune_end without sdmi_tune_begin");
+  if (tune_drain()) return -1;
+  g_tuner.collecting = false;
+  for (auto& kv : g_tuner.stats) {
+    double best = 1e30; const TuneChoice* bc = nullptr;
+    for (auto& c : kv.second)
+      if (c.second.second > 0 && c.second.first / c.second.second < best) { best = c.second.first / c.second.second; bc = &c.first; }
+    if (bc) g_tuner.table[kv.first] = {bc->tile, bc->splitk, best};
+  }
+  if (n_keys) *n_keys = (int)g_tuner.stats.size();
+  const std::string out = (path && *path) ? std::string(path) : Tuner::default_path();
+  FILE* f = fopen(out.c_str(), "w");
+  if (!f) return fail("cannot write the tuning table to " + out);
+  fprintf(f, "# libsdmi igemm tuning table (gfx950), measured in situ by tools/tune.py -- M N K ksize stride up mode splitk_req tile splitk us\n");
+  for (auto& kv : g_tuner.table) {
+    const TuneKey& k = kv.first;
+    fprintf(f, "%d %d %d %d %d %d %d %d %d %d %.2f\n", k.M, k.N, k.K, k.ksize, k.stride, k.up, k.mode, k.splitk_req, kv.second.tile,
+            kv.second.splitk, kv.second.us);
+  }
+  fclose(f);
+  return 0;
+}
+// per-candidate timings of the last collection as text lines (for profiles/): key | tile splitk us n
+int tune_dump(std::string* out) {
+  std::lock_guard<std::mutex> lk(g_tuner.mu);
+  char buf[256];
+  for (auto& kv : g_tuner.stats) {
+    const TuneKey& k = kv.first;
+    for (auto& c : kv.second) {
+      if (!c.second.second) continue;
+      snprintf(buf, sizeof buf, "%d %d %d %d %d %d %d %d | %d %d %.2f %d\n", k.M, k.N, k.K, k.ksize, k.stride, k.up, k.mode,
+               k.splitk_req, c.first.tile, c.first.splitk, c.second.first / c.second.second, c.second.second);
+      *out += buf;
+    }
+  }
+  return 0;
+}
+
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream) {
   SDMI_CHECK(p.M > 0 && p.N > 0 && p.K > 0, "empty GEMM");
   SDMI_CHECK(p.ksize == 1 || p.ksize == 3, "ksize must be 1 or 3");
@@ -600,8 +906,6 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   SDMI_CHECK(p.c2 == 0 || (p.a2 != nullptr && p.lda2 % 8 == 0), "third A source missing");
   SDMI_CHECK((p.c1 == 0 || p.lda1 == p.lda0) && (p.c2 == 0 || p.lda2 == p.lda0), "all A sources must share one row pitch");
   SDMI_CHECK(!p.up || (p.ksize == 3 && p.stride == 1), "upsample folding needs a 3x3 stride-1 conv");
-  SDMI_CHECK((int64_t)p.B * p.Hin * p.Win * p.lda0 < (int64_t)1 << 31 && (int64_t)p.N * p.K < (int64_t)1 << 31,
-             "tensor too large for 32-bit element offsets");
   if (p.mode == EPI_GEGLU) SDMI_CHECK(p.N % 64 == 0 && p.out_f16 != nullptr, "GEGLU needs N % 64 == 0 and an fp16 output");
   if (p.ln_out)
     SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && p.ldo == p.N && p.N % 4 == 0 && p.N <= 2560 && p.ln_gamma && p.ln_beta,
@@ -609,42 +913,59 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   if (p.out_lo) SDMI_CHECK(p.mode == EPI_PLAIN && p.ldo % 4 == 0, "out_lo needs plain mode");
   if (p.mode == EPI_HEADS) SDMI_CHECK(p.segC > 0 && p.dh > 0 && p.N % p.segC == 0 && p.N / p.segC <= 3, "bad head scatter");
 
+  SDMI_CHECK((int64_t)p.B * p.Hin * p.Win * p.lda0 * 2 + (int64_t)(p.Win + 1) * p.lda0 * 2 < ((int64_t)1 << 31) - 65536 &&
+                 (int64_t)p.N * p.K * 2 < ((int64_t)1 << 31) - 65536,
+             "tensor too large for 31-bit byte offsets (buffer addressing)");
   static const int env_dma = env_int("SDMI_IGEMM_DMA", 1);
   static const int env_tile = env_int("SDMI_IGEMM_TILE", -1);
   const bool dma = (tune.dma >= 0 ? tune.dma : env_dma) != 0;
   int tile = tune.tile >= 0 ? tune.tile : env_tile;
-  static const int env_geglu = env_int("SDMI_TILE_GEGLU", 0);
-  if (p.mode == EPI_GEGLU && !(tile == 0 || tile == 3 || tile == 6 || tile == 7)) tile = env_geglu;   // GEGLU pairs 32-col tiles inside a wave
-  // Tile / split-K choice, from the per-shape sweep of tests/tools/bench_kernels.py on MI355X (profiles/kbench_r01.txt):
-  // every shape of this UNet is bound by L2->LDS bytes in flight, so the many-block 64x64 tile wins except for
-  // the few >= 25 GFLOP convs, where the 256x128 tile (fewest bytes per FLOP) is ~10 % faster.
-  const double gflop = 2.0 * p.M * (double)p.N * p.K * 1e-9;
-  if (tile < 0) {
-    static const int env_small = env_int("SDMI_TILE_SMALL", 5);       // tuning knobs for same-box A/B runs (tools/gpu_ab.sh)
-    static const int env_t5kt = env_int("SDMI_T5_MIN_KT", 0);         // 3-stage tile only when K has >= this many k-tiles
-    static const int env_heads = env_int("SDMI_TILE_HEADS", 2);
-    static const int env_t3 = env_int("SDMI_T3_GFLOP", 25);
-    static const int env_big = env_int("SDMI_TILE_BIG", 3);
-    if (p.mode == EPI_HEADS) tile = env_heads;
-    else tile = (gflop >= (double)env_t3) ? env_big : ((env_small == 5 && p.K / BK < env_t5kt) ? 2 : env_small);
-  }
-  const int BMs[8] = {128, 128, 64, 256, 128, 64, 256, 128}, BNs[8] = {128, 64, 64, 128, 64, 64, 128, 128};
+  SDMI_CHECK(tile < SDMI_NUM_TILES, "unknown igemm tile id");
   int splitk = p.splitk;
   const int nkt = p.K / BK;
   static const int env_split = env_int("SDMI_SPLITK", -1);     // 1 disables split-K everywhere
   const bool can_split_plain = p.mode == EPI_PLAIN && p.splitk_ws && p.N % 4 == 0 && p.ldo % 4 == 0 &&
                                (p.residual == nullptr || p.ldr % 4 == 0);
-  // (the executors keep the head-scatter GEMMs unsplit: a same-box A/B showed split-K + reduce no faster there)
   const bool can_split_heads = p.mode == EPI_HEADS && p.splitk_ws && p.dh % 4 == 0 && p.segC % 4 == 0;
   const bool can_split = can_split_plain || can_split_heads;
   if (env_split >= 0 && splitk == 0) splitk = env_split;
+
+  // ---- (tile, split-K): explicit request > tuning table / collection run > heuristic ------------------------------
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  TuneKey tkey{p.M, p.N, p.K, p.ksize, p.stride, p.up, p.mode, splitk};
+  int tcand = -1;
+  if (tile < 0) {
+    std::lock_guard<std::mutex> lk(g_tuner.mu);
+    g_tuner.ensure_loaded();
+    if (g_tuner.collecting) {
+      IGemmParams q = p; q.splitk = splitk;
+      const std::vector<TuneChoice> cands = tune_candidates(q, can_split);
+      auto& st = g_tuner.stats[tkey];
+      if (st.empty()) for (auto& c : cands) st.push_back({c, {0.0, 0}});
+      tcand = g_tuner.round % (int)cands.size();
+      tile = cands[tcand].tile; splitk = cands[tcand].splitk;
+      ev0 = g_tuner.ev(); ev1 = g_tuner.ev();
+    } else {
+      auto it = g_tuner.table.find(tkey);
+      if (it != g_tuner.table.end() && (it->second.splitk == 1 || (can_split && (int64_t)it->second.splitk * p.M * p.N <= p.splitk_ws_floats)) &&
+          (p.mode != EPI_GEGLU || tile_tn_even(it->second.tile))) {
+        tile = it->second.tile; splitk = it->second.splitk;
+      }
+    }
+  }
+  if (p.mode == EPI_GEGLU && tile >= 0 && !tile_tn_even(tile)) tile = 0;   // GEGLU pairs 32-col tiles inside a wave
+  if (tile < 0) {
+    // heuristic for shapes the table does not know (round-1 sweep: the many-block 64x64 tile except for >= 25 GFLOP)
+    const double gflop = 2.0 * p.M * (double)p.N * p.K * 1e-9;
+    if (p.mode == EPI_GEGLU) tile = 0;
+    else if (p.mode == EPI_HEADS) tile = 2;
+    else tile = gflop >= 25.0 ? 3 : 5;
+  }
   if (splitk <= 0) {  // auto: enough blocks to keep bytes in flight on all 256 CUs, >= 8 k-tiles per split
     splitk = 1;
     if (can_split) {
-      const long blocks = (long)cdiv(p.M, BMs[tile]) * cdiv(p.N, BNs[tile]);
-      static const int env_want = env_int("SDMI_SPLIT_WANT", 512);
-      static const int env_want3 = env_int("SDMI_SPLIT_WANT3", 160);
-      const long want = (tile == 3 || tile == 6) ? env_want3 : env_want;
+      const long blocks = (long)cdiv(p.M, kTiles[tile].bm) * cdiv(p.N, kTiles[tile].bn);
+      const long want = (kTiles[tile].wm * kTiles[tile].wn == 8) ? 160 : 512;
       while (blocks * splitk < want && nkt / (splitk * 2) >= 8 && splitk < 16 &&
              (int64_t)(splitk * 2) * p.M * p.N <= p.splitk_ws_floats)
         splitk *= 2;
@@ -654,17 +975,14 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     SDMI_CHECK(can_split, "split-K needs plain or head-scatter mode, a slab workspace and N / ldo / ldr multiples of 4");
     SDMI_CHECK((int64_t)splitk * p.M * p.N <= p.splitk_ws_floats, "split-K workspace too small");
   }
-  switch (tile) {            // tile ids: see include/sdmi.h (sdmi_igemm_desc.tile)
-    case 0: return launch_cfg<128, 128, 2, 2, 2>(p, dma, splitk, stream);
-    case 1: return launch_cfg<128, 64, 2, 2, 2>(p, dma, splitk, stream);
-    case 2: return launch_cfg<64, 64, 2, 2, 2>(p, dma, splitk, stream);
-    case 3: return launch_cfg<256, 128, 4, 2, 2>(p, dma, splitk, stream);
-    case 4: return launch_cfg<128, 64, 2, 2, 3>(p, dma, splitk, stream);
-    case 5: return launch_cfg<64, 64, 2, 2, 3>(p, dma, splitk, stream);
-    case 6: return launch_cfg<256, 128, 4, 2, 3>(p, dma, splitk, stream);
-    case 7: return launch_cfg<128, 128, 2, 2, 3>(p, dma, splitk, stream);
-    default: return fail("unknown igemm tile id");
+  if (ev0) SDMI_HIP_OK(hipEventRecord(ev0, stream));
+  const int rc = launch_tile(tile, p, dma, splitk, stream);
+  if (ev0) {
+    SDMI_HIP_OK(hipEventRecord(ev1, stream));
+    std::lock_guard<std::mutex> lk(g_tuner.mu);
+    g_tuner.recs.push_back({tkey, tcand, ev0, ev1});
   }
+  return rc;
 }
 
 }  // namespace sdmi

@@ -321,6 +321,7 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
   if (rc) return rc;
   s.set = true;
   finalized_ = false;
+  ctx_valid_ = false;      // cached cross-attention K/V were computed with the previous to_k / to_v weights
   return 0;
 }
 

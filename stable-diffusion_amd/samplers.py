@@ -253,12 +253,14 @@ class DDIMSamplerHIP(_SamplerBase):
                 ts = torch.full((b,), int(step), device=device, dtype=torch.long)
                 img = (self.model.q_sample(x0, ts) * mask + (1. - mask) * img).float().contiguous()
             eps = self._model_eps(x_in, img, int(step), c_in, cfg, b)
-            noise = None
-            if float(self._tab['sigmas'][index]) != 0.0:
-                noise = torch.randn(img.shape, device=device) * temperature        # ddim.py:200
-                if noise_dropout > 0.:
-                    noise = torch.nn.functional.dropout(noise, p=noise_dropout)
-                noise = noise.float().contiguous()
+            # ddim.py:200 draws noise_like() on EVERY step, also at eta = 0 where sigma_t = 0 and the term vanishes: draw it
+            # too, so the device RNG stream stays where the reference's is (the x_T of a later n_iter comes from it);
+            # the kernel only reads it when sigma_t != 0.  The reference multiplies sigma_t * noise first, then the
+            # temperature: the step kernel takes the product noise * temperature (identical at the default temperature 1).
+            noise = torch.randn(img.shape, device=device) * temperature
+            if noise_dropout > 0.:
+                noise = torch.nn.functional.dropout(noise, p=noise_dropout)
+            noise = noise.float().contiguous() if float(self._tab['sigmas'][index]) != 0.0 else None
             x_prev = torch.empty_like(img)
             pred_x0 = torch.empty_like(img)
             self._step(eps, cfg, scale, img, 0, [], index, None, x_prev, pred_x0, noise)

@@ -113,27 +113,40 @@ class UNetModelHIP(nn.Module):
                 node = node._modules[name]
             node.register_parameter(leaf, nn.Parameter(torch.zeros(shape), requires_grad=False))
         self._packed_sig = None
+        self._from_blob = False       # weights came from load_packed(): the nn.Parameters are NOT the weight source
         self._sentinels = None
         self._ws = None
         self._ctx_ref = None
         self._ctx_ver = None
         self._ctx_shape = None
         self._pinned = None
+        self._pinned_ctx = None
 
     # ---- weights -> library ---------------------------------------------------------------------------
     # Re-pack whenever the parameters may have changed: device moves / dtype casts (_apply), load_state_dict,
     # or an explicit mark_dirty() after in-place edits.  A cheap per-call check of a few sentinel tensors catches
     # the common in-place cases without walking all 686 parameters on the hot path.
+    # After load_packed() the library's packed buffers are the only weight source (the parameters stay at their zero
+    # initialisation): a device move / dtype cast must then NOT trigger a repack from the parameters -- that would
+    # silently replace the blob with all-zero weights.  load_state_dict() / mark_dirty() hand the role back to the parameters.
     def _apply(self, fn, *a, **k):
-        self._packed_sig = None
+        if not self._from_blob:
+            self._packed_sig = None
         return super()._apply(fn, *a, **k)
 
     def load_state_dict(self, *a, **k):
         self._packed_sig = None
+        self._from_blob = False
         return super().load_state_dict(*a, **k)
 
     def mark_dirty(self):
         self._packed_sig = None
+        self._from_blob = False
+
+    def _needs_pack(self):
+        if self._from_blob:
+            return False
+        return self._packed_sig is None or self._packed_sig != self._signature()
 
     def _signature(self):
         if getattr(self, '_sentinels', None) is None:
@@ -159,13 +172,14 @@ class UNetModelHIP(nn.Module):
         _lib.check(lib.sdmi_unet_finalize(self._handle.h))
         self._sentinels = None
         self._packed_sig = self._signature()
+        self._from_blob = False
         self._ctx_ref = None
 
     # ---- packed-weight blob --------------------------------------------------------------------------
     def save_packed(self, path):
         """Write the library's packed fp16 weights (after pack()) to `path`: header + buffers, mmap-able."""
         import numpy as np
-        if self._packed_sig is None or self._packed_sig != self._signature():
+        if self._needs_pack():
             self.pack()
         lib = self._handle.lib
         n = int(lib.sdmi_unet_packed_bytes(self._handle.h))
@@ -185,6 +199,7 @@ class UNetModelHIP(nn.Module):
                                                             _lib.stream_ptr()))
         self._sentinels = None
         self._packed_sig = self._signature()
+        self._from_blob = True
         self._ctx_ref = None
         return self
 
@@ -200,26 +215,40 @@ class UNetModelHIP(nn.Module):
     # ---- context pinning (used by the HIP samplers) ------------------------------------------------------------
     def pin_context(self, context):
         """Compute the cross-attention K/V of every SpatialTransformer for `context` once (attention.py:174-176
-        depend on the context only) and reuse them for every forward() until unpin_context().  The caller promises
-        to keep passing a context with the same contents (the sampler loop does: c_in is constant over the steps)."""
+        depend on the context only) and reuse them for every forward() until unpin_context().  A forward() that gets a
+        different tensor object is compared with the pinned contents (one small device compare) and, if it differs,
+        recomputes its K/V -- an img_callback or a second sampler sharing the UNet never sees stale K/V."""
         if not context.is_cuda:
             raise RuntimeError('UNetModelHIP runs on an MI355X device tensor only (no CPU fallback)')
-        if self._packed_sig is None or self._packed_sig != self._signature():
+        if self._needs_pack():
             self.pack()
         B, L, D = context.shape
         assert D == self.context_dim
+        if B > self.MAX_ROWS:           # the library caches K/V for one call of <= 8 rows: chunked batches recompute them
+            self._pinned = None
+            return
         down = 2 ** (len(self.channel_mult) - 1)
         ws = self._workspace(B, down, down, L, context.device)
         ctx32 = context.detach().float().contiguous()
         _lib.check(self._handle.lib.sdmi_unet_cache_context(self._handle.h, ctx32.data_ptr(), B, L, ws.data_ptr(),
                                                             ws.numel(), _lib.stream_ptr()))
         self._pinned = (B, L)
+        self._pinned_ctx = (context, context._version, ctx32.clone() if ctx32 is context else ctx32)
         self._ctx_ref = None
 
     def unpin_context(self):
         self._pinned = None
+        self._pinned_ctx = None
+
+    def _pinned_matches(self, context):
+        ref, ver, saved = self._pinned_ctx
+        if context is ref and context._version == ver:
+            return True
+        return bool(torch.equal(context.detach().float(), saved))
 
     # ---- UNetModel.forward (openaimodel.py:710-742) ----------------------------------------------------------
+    MAX_ROWS = 8      # rows per library call (sdmi_unet_forward); larger batches are split, rows are independent
+
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
         assert y is None, 'must specify y if and only if the model is class-conditional'
@@ -227,23 +256,38 @@ class UNetModelHIP(nn.Module):
             raise RuntimeError('UNetModelHIP runs on an MI355X device tensor only (no CPU fallback)')
         if context is None or timesteps is None:
             raise ValueError('timesteps and context are required')
-        if self._packed_sig is None or self._packed_sig != self._signature():
+        if self._needs_pack():
             self.pack()
         B, Cin, H, W = x.shape
         assert Cin == self.in_channels
+        assert timesteps.shape == (B,)
+        assert context.dim() == 3 and context.shape[0] == B and context.shape[2] == self.context_dim
+        if B > self.MAX_ROWS:
+            # e.g. `txt2img.py --n_samples 5` = CFG batch 10 (scripts/txt2img.py:110-114): the reference has no
+            # cross-sample op (GroupNorm and attention are per sample), so the batch is evaluated in chunks of <= 8 rows
+            outs = [self._forward_rows(x[i:i + self.MAX_ROWS], timesteps[i:i + self.MAX_ROWS],
+                                       context[i:i + self.MAX_ROWS], allow_reuse=False)
+                    for i in range(0, B, self.MAX_ROWS)]
+            return torch.cat(outs, dim=0)
+        return self._forward_rows(x, timesteps, context, allow_reuse=True)
+
+    def _forward_rows(self, x, timesteps, context, allow_reuse):
+        B, Cin, H, W = x.shape
         x32 = x.detach().float().contiguous()
         if timesteps.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8):
             t_i64, t_f32 = timesteps.detach().to(torch.int64).contiguous(), None
         else:
             t_i64, t_f32 = None, timesteps.detach().float().contiguous()
-        assert (t_i64 if t_i64 is not None else t_f32).shape == (B,)
-        assert context.dim() == 3 and context.shape[0] == B and context.shape[2] == self.context_dim
         L = context.shape[1]
         ws = self._workspace(B, H, W, L, x.device)
-        # cross-attention K/V depend on the context only: skip their recomputation while the caller keeps
-        # passing the very same (unmodified) tensor object
-        reuse = (self._pinned == (B, L)) or \
-            ((self._ctx_ref is context) and (self._ctx_ver == context._version) and self._ctx_shape == (B, L))
+        # cross-attention K/V depend on the context only: skip their recomputation while the context is pinned (and
+        # still has the pinned contents) or the caller keeps passing the very same, unmodified tensor object
+        reuse = False
+        if allow_reuse:
+            if self._pinned == (B, L):
+                reuse = self._pinned_matches(context)
+            else:
+                reuse = (self._ctx_ref is context) and (self._ctx_ver == context._version) and self._ctx_shape == (B, L)
         ctx32 = None
         if not reuse:
             ctx32 = context.detach().float().contiguous()
@@ -251,6 +295,13 @@ class UNetModelHIP(nn.Module):
         _lib.check(self._handle.lib.sdmi_unet_forward(
             self._handle.h, x32.data_ptr(), _lib.ptr(t_i64), _lib.ptr(t_f32), _lib.ptr(ctx32), out.data_ptr(),
             B, H, W, L, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
-        if self._pinned is None:
-            self._ctx_ref, self._ctx_ver, self._ctx_shape = context, context._version, (B, L)
+        if not reuse:
+            # the library's K/V cache now holds THIS context: a pin for other contents is void, and the identity
+            # shortcut only applies to un-chunked calls
+            if self._pinned == (B, L):
+                self._pinned, self._pinned_ctx = None, None
+            if allow_reuse:
+                self._ctx_ref, self._ctx_ver, self._ctx_shape = context, context._version, (B, L)
+            else:
+                self._ctx_ref = None
         return out

@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 5
+    assert lib.sdmi_abi_version() == 6
     for name in declared:
         assert hasattr(lib, name)
 
@@ -205,7 +205,7 @@ def test_plugin_seam_against_the_real_reference():
     sys.path.insert(0, '/root/reference')
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import run_reference_script as launcher
-    launcher.install_stubs(have_gpu=True)          # stand-ins only; nn.Module.cuda stays untouched
+    launcher.install_stubs(have_gpu=True, offline_stubs=True)   # stand-ins only; nn.Module.cuda stays untouched
     from ldm.util import instantiate_from_config
     cfg = yaml.safe_load(open('/root/reference/configs/stable-diffusion/v1-inference.yaml'))
     unet_cfg = cfg['model']['params']['unet_config']

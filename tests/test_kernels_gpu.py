@@ -38,6 +38,10 @@ CONV_CASES = [
     ('conv3_cat', 2, 8, 8, 64, 128, 64, 3, 1, 0),
     ('conv1_cat', 2, 8, 8, 128, 64, 320, 1, 1, 0),
     ('tiny_m', 1, 2, 2, 256, 0, 256, 3, 1, 0),
+    # long K (20 / 45 k-tiles through the 2..4-stage LDS-DMA ring), M and N tails inside the largest tiles
+    ('dense_longk', 1, 300, 1, 1280, 0, 200, 1, 1, 0),
+    ('conv3_longk', 1, 9, 11, 320, 0, 320, 3, 1, 0),
+    ('conv3_up_odd', 1, 5, 7, 128, 0, 72, 3, 1, 1),
 ]
 
 
@@ -51,7 +55,10 @@ def _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up):
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-@pytest.mark.parametrize('tile', [0, 1, 2, 3, 4, 5, 6, 7])
+ALL_TILES = list(range(14))     # include/sdmi.h: sdmi_igemm_desc.tile
+
+
+@pytest.mark.parametrize('tile', ALL_TILES)
 @pytest.mark.parametrize('dma', [0, 1])
 def test_igemm_conv(case, tile, dma):
     name, B, Hin, Win, c0, c1, N, ksize, stride, up = case
@@ -84,7 +91,7 @@ def test_igemm_conv(case, tile, dma):
 
 
 @pytest.mark.parametrize('splitk', [0, 2, 5])
-@pytest.mark.parametrize('tile', [0, 2, 3])
+@pytest.mark.parametrize('tile', [0, 2, 3, 7, 8, 9, 11, 12, 13])
 def test_igemm_splitk_inplace_residual(splitk, tile):
     g = _g(5)
     B, H, W, C, N = 2, 4, 4, 256, 192
@@ -167,7 +174,7 @@ def test_igemm_geglu():
     val, gate = y.chunk(2, dim=-1)
     ref = val * F.gelu(gate)
     wp, bp = K.pack_geglu(w.float().to(DEV), b.to(DEV))
-    for tile in (0, 3, 6, 7):
+    for tile in (0, 3, 6, 7, 8, 9, 11, 12, 13):      # every tile whose waves own an even number of 32-column MFMA tiles
         out = torch.full((M, N // 2), float('nan'), device=DEV, dtype=torch.float16)
         K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1, tile=tile)
         torch.cuda.synchronize()
@@ -356,7 +363,7 @@ def test_time_embedding_path():
         assert K.report(f'small_linear silu{silu}', outl, refl, 2e-5) < 2e-5
 
 
-@pytest.mark.parametrize('tile', [0, 2, 3])
+@pytest.mark.parametrize('tile', [0, 2, 3, 7, 9, 12, 13])
 @pytest.mark.parametrize('B,H,W,C,N', [(2, 12, 12, 64, 128), (1, 6, 10, 128, 64)])
 def test_igemm_conv_stride2_asym_pad(tile, B, H, W, C, N):
     """VAE Downsample (ldm/modules/diffusionmodules/model.py:72-76): F.pad(x,(0,1,0,1)) + conv3x3(stride 2, padding 0)."""

@@ -36,8 +36,10 @@ def _model(cfg_name, wseed):
     return _models[key]
 
 
+# *_t1_741: t in {1, 741} (the batch-2 cases only see 981 / 481); *_b6: CFG batch 6 = txt2img's default n_samples 3
+# (scripts/txt2img.py:110-114); tiny_b10: more than 8 rows per call (n_samples 5), chunked by UNetModelHIP.forward
 CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64',
-         'sdv1_96x96']
+         'sdv1_96x96', 'sdv1_t1_741_16x16', 'sdv1_b6_16x16', 'tiny_b6_16x16', 'tiny_b10_8x8']
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -47,7 +49,7 @@ def test_unet_eps_matches_reference_golden(case, golden_dir):
     cfg = CFGS[cfg_name]
     m, sd = _model(cfg_name, int(z['weight_seed']))
     x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
-                            ctx_len=int(z['ctx_len']))
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
     assert torch.equal(t, torch.from_numpy(z['t']))
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     torch.cuda.synchronize()
@@ -126,9 +128,22 @@ def test_batch_rows_are_independent(cfg_name, B, h, w):
         worst = max(worst, (one - whole[i:i + 1]).abs().max().item())
     print(f'[unet batch {cfg_name} B={B} {h}x{w}] batched vs row-by-row max-abs {worst:.3e}', flush=True)
     assert worst <= 2 * TOL
-    with pytest.raises(RuntimeError):
-        m(torch.zeros(9, cfg.in_channels, 8, 8, device='cuda'), torch.zeros(9, dtype=torch.long, device='cuda'),
-          context=torch.zeros(9, 77, cfg.context_dim, device='cuda'))        # > 8 rows per call is refused, not truncated
+
+
+def test_more_than_8_rows_is_chunked():
+    """`txt2img.py --n_samples 5` is a CFG batch of 10: the library takes <= 8 rows per call, UNetModelHIP.forward splits the
+    batch (rows are independent) -- bit-identical to calling the chunks by hand, with and without a pinned context."""
+    m, sd = _model('tiny', 0)
+    x, t, ctx = make_inputs(TINY, 19, 8, 8, seed=13)
+    xc, tc, cc = x.cuda(), t.cuda(), ctx.cuda()
+    whole = m(xc, tc, context=cc)
+    parts = torch.cat([m(xc[i:i + 8].contiguous(), tc[i:i + 8].contiguous(), context=cc[i:i + 8].contiguous())
+                       for i in range(0, 19, 8)])
+    assert whole.shape == (19, TINY.out_channels, 8, 8) and torch.equal(whole, parts)
+    m.pin_context(cc)
+    pinned = m(xc, tc, context=cc)
+    m.unpin_context()
+    assert torch.equal(whole, pinned)
 
 
 def test_packed_weight_blob_round_trip(tmp_path):
@@ -146,6 +161,14 @@ def test_packed_weight_blob_round_trip(tmp_path):
     fresh = UNetModelHIP(**kw).cuda().load_packed(path)          # parameters stay zero: the blob is the only weight source
     out = fresh(x.cuda(), t.cuda(), context=ctx.cuda())
     assert torch.equal(out, ref)
+    # a device move / dtype cast after load_packed (what load_model_from_config's model.cuda() and
+    # LatentDiffusionHIP(unet).to(device) do) must not repack the all-zero parameters over the blob
+    fresh = fresh.to('cuda').float()
+    assert torch.equal(fresh(x.cuda(), t.cuda(), context=ctx.cuda()), ref)
+    fresh2 = UNetModelHIP(**kw).load_packed(path).cuda()        # blob first, .cuda() afterwards
+    assert torch.equal(fresh2(x.cuda(), t.cuda(), context=ctx.cuda()), ref)
+    fresh2.load_state_dict(sd, strict=True)                      # real parameters again: the blob flag is dropped
+    assert torch.equal(fresh2(x.cuda(), t.cuda(), context=ctx.cuda()), ref)
     other = UNetModelHIP(**dict(kw, num_res_blocks=kw['num_res_blocks'] + 1)).cuda()
     with pytest.raises(SdmiError, match='different UNet configuration'):
         other.load_packed(path)

@@ -3,10 +3,13 @@
     python tools/run_reference_script.py [--hip] [--reference /root/reference] txt2img -- --plms --ddim_steps 50 ...
 
 What this launcher does (nothing in the reference tree is edited or copied):
-  * puts minimal stand-ins into `sys.modules` for the third-party imports the scripts need but an offline box lacks
+  * puts minimal stand-ins into `sys.modules` for the third-party imports the scripts need but THIS box lacks
     (SURVEY.md 8b): omegaconf, pytorch_lightning, torchvision.utils, cv2, imwatermark, diffusers' safety checker,
-    taming, clip, kornia; the HF `from_pretrained` calls (CLIP tokenizer / text model, safety feature extractor) get
-    seeded random-init stand-ins because there is no network;
+    taming, clip, kornia -- each only when the real package fails to import;
+  * the HF `from_pretrained` calls (CLIP tokenizer / text model, safety feature extractor) and the safety checker try
+    the REAL thing first; only when that fails (no network / no cache) AND `--offline-stubs` was given do they fall back
+    to seeded random-init stand-ins, each with a loud warning.  With a real `--ckpt` path the stand-ins are refused:
+    a byte-hash tokenizer and a disabled safety checker must never run silently beside real weights;
   * `--ckpt synthetic[:seed]` makes `torch.load` return a seeded random UNet + first-stage state_dict under the
     checkpoint's key names (`model.diffusion_model.*`, `first_stage_model.*`) -- there is no SD checkpoint in the
     environment; a real `--ckpt path` is loaded as usual;
@@ -73,7 +76,11 @@ class ListConfig(list):
     pass
 
 
-def install_stubs(have_gpu):
+def _warn(msg):
+    print('\n' + '!' * 100 + f'\n!! run_reference_script: {msg}\n' + '!' * 100 + '\n', file=sys.stderr, flush=True)
+
+
+def install_stubs(have_gpu, offline_stubs=False, real_ckpt=False):
     import yaml
     import transformers          # before the stand-ins: it probes optional packages (torchvision, ...) via find_spec
 
@@ -145,11 +152,35 @@ def install_stubs(have_gpu):
             def encode(self, img, method): return img
         _module('imwatermark', WatermarkEncoder=WatermarkEncoder)
 
+    def _stand_in_allowed(what):
+        """The stand-ins for network-bound pieces are opt-in and never combined with a real checkpoint."""
+        if real_ckpt:
+            raise SystemExit(f'{what} is not available offline and a real --ckpt was given: refusing to substitute a '
+                             'stand-in (prompts would be tokenized into garbage / the safety filter would be off). '
+                             'Provide the HF cache, or use --ckpt synthetic with --offline-stubs.')
+        if not offline_stubs:
+            raise SystemExit(f'{what} is not available offline; pass --offline-stubs to run with a seeded stand-in '
+                             '(synthetic checkpoints only)')
+
     class _Safety:
         @classmethod
         def from_pretrained(cls, *a, **k): return cls()
         def __call__(self, images, clip_input): return images, [False] * len(images)
-    if 'diffusers' not in sys.modules:
+    try:
+        import diffusers.pipelines.stable_diffusion.safety_checker as _sc   # noqa: F401
+        _real_sc = _sc.StableDiffusionSafetyChecker.from_pretrained.__func__
+
+        def _safety_from_pretrained(cls, *a, **k):
+            try:
+                return _real_sc(cls, *a, **k)
+            except Exception as e:      # no network / no cache
+                _stand_in_allowed(f'the NSFW safety checker weights ({type(e).__name__})')
+                _warn('SAFETY CHECKER STUBBED: every image is reported as safe (has_nsfw = False)')
+                return _Safety()
+        _sc.StableDiffusionSafetyChecker.from_pretrained = classmethod(_safety_from_pretrained)
+    except ImportError:
+        _stand_in_allowed('the `diffusers` package (NSFW safety checker)')
+        _warn('SAFETY CHECKER STUBBED (diffusers is not installed): every image is reported as safe')
         _module('diffusers.pipelines.stable_diffusion.safety_checker', StableDiffusionSafetyChecker=_Safety)
 
     for name in ('clip', 'kornia', 'taming', 'taming.modules', 'taming.modules.vqvae'):
@@ -157,13 +188,24 @@ def install_stubs(have_gpu):
             _module(name)
     _module('taming.modules.vqvae.quantize', VectorQuantizer2=type('VectorQuantizer2', (nn.Module,), {}))
 
-    # ---- HF from_pretrained (network) -> seeded random-init stand-ins ---------------------------------------------
+    # ---- HF from_pretrained: the real call first; a seeded stand-in only offline, opt-in, with a warning ----------
     import transformers
+
+    def _try_real(cls_name, what, make_stub):
+        real = getattr(transformers, cls_name).from_pretrained.__func__
+
+        def from_pretrained(cls, *a, **k):
+            try:
+                return real(cls, *a, **k)
+            except Exception as e:      # no network / nothing in the HF cache
+                _stand_in_allowed(f'{what} ({type(e).__name__}: HF hub unreachable and not cached)')
+                _warn(f'{what.upper()} STUBBED with a seeded stand-in -- outputs are NOT those of the real model')
+                return make_stub()
+        getattr(transformers, cls_name).from_pretrained = classmethod(from_pretrained)
 
     class _FeatureExtractor:
         def __call__(self, images, return_tensors='pt'):
             return types.SimpleNamespace(pixel_values=torch.zeros(len(images), 3, 224, 224))
-    transformers.AutoFeatureExtractor.from_pretrained = classmethod(lambda cls, *a, **k: _FeatureExtractor())
 
     class _Tokenizer:
         """deterministic stand-in: bytes of the prompt -> ids, BOS/EOS/pad like CLIP's (49406 / 49407)."""
@@ -175,14 +217,15 @@ def install_stubs(have_gpu):
                 toks = [49406] + [1000 + (b * 37) % 40000 for b in s.encode()][:max_length - 2] + [49407]
                 ids[i, :len(toks)] = torch.tensor(toks)
             return {'input_ids': ids}
-    transformers.CLIPTokenizer.from_pretrained = classmethod(lambda cls, *a, **k: _Tokenizer())
 
-    def _clip_text(cls, *a, **k):
+    def _clip_text():
         cfg = transformers.CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
                                           num_attention_heads=12, max_position_embeddings=77, hidden_act='quick_gelu')
         torch.manual_seed(1234)
         return transformers.CLIPTextModel(cfg)
-    transformers.CLIPTextModel.from_pretrained = classmethod(_clip_text)
+    _try_real('AutoFeatureExtractor', 'the safety feature extractor', _FeatureExtractor)
+    _try_real('CLIPTokenizer', 'the CLIP tokenizer', _Tokenizer)
+    _try_real('CLIPTextModel', 'the CLIP text model weights', _clip_text)
 
     if not have_gpu:   # configs[0]: CPU plumbing run
         nn.Module.cuda = lambda self, device=None: self
@@ -213,6 +256,9 @@ def main():
     ap = argparse.ArgumentParser(description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument('--reference', default=os.environ.get('SD_REFERENCE', '/root/reference'))
     ap.add_argument('--hip', action='store_true', help='UNetModelHIP + HIP samplers (needs the MI355X)')
+    ap.add_argument('--offline-stubs', action='store_true',
+                    help='allow seeded stand-ins for the CLIP tokenizer / text model / safety checker when the HF hub is '
+                         'unreachable (synthetic checkpoints only; each substitution prints a warning)')
     ap.add_argument('script', choices=['txt2img', 'img2img'])
     ap.add_argument('rest', nargs=argparse.REMAINDER)
     args = ap.parse_args()
@@ -223,7 +269,9 @@ def main():
     have_gpu = torch.cuda.is_available()
     if args.hip and not have_gpu:
         raise SystemExit('--hip needs the MI355X (the HIP path has no CPU fallback)')
-    install_stubs(have_gpu)
+    ckpt = rest[rest.index('--ckpt') + 1] if '--ckpt' in rest and rest.index('--ckpt') + 1 < len(rest) else None
+    real_ckpt = not (ckpt or '').startswith('synthetic')     # the script's default --ckpt is a real file as well
+    install_stubs(have_gpu, offline_stubs=args.offline_stubs, real_ckpt=real_ckpt)
     patch_torch_load()
 
     import ldm.models.diffusion.ddim as ddim
