@@ -32,17 +32,33 @@ import torch  # noqa: E402
 
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
-UNET_GFLOP_64 = 1606.5        # one UNet call, CFG batch 2, latent 64x64
+UNET_GFLOP = {64: 1606.5, 96: 4296.2}     # one UNet call, CFG batch 2, latent 64x64 / 96x96
+
+# BASELINE.json configs: [1] is the headline (and the default); [3] and [4] are measured with --workload
+WORKLOADS = {
+    'txt2img512': dict(latent=64, sampler='plms', steps=50, scale=7.5, calls=51, vae_parts=1,
+                       metric='512x512 images/sec, SD-v1-4 50-step PLMS CFG=7.5',
+                       desc='latent 4x64x64 (512x512), 50 PLMS steps = 51 UNet calls at CFG batch 2, scale 7.5'),
+    'txt2img768': dict(latent=96, sampler='ddim', steps=50, scale=7.5, calls=50, vae_parts=1,
+                       metric='768x768 images/sec, SD-v1-4 50-step DDIM CFG=7.5',
+                       desc='latent 4x96x96 (768x768, 9216-token self-attention), 50 DDIM steps = 50 UNet calls at CFG '
+                            'batch 2, scale 7.5 (scripts/txt2img.py --H 768 --W 768, BASELINE.json configs[3])'),
+    'img2img512': dict(latent=64, sampler='img2img', steps=50, scale=5.0, calls=37, vae_parts=3, strength=0.75,
+                       metric='512x512 img2img images/sec, SD-v1-4 strength 0.75 of 50 DDIM steps CFG=5.0',
+                       desc='first-stage encode of a 512x512 image, stochastic_encode at t_enc = 37, 37 DDIM steps at CFG '
+                            'batch 2, scale 5.0 (scripts/img2img.py defaults, BASELINE.json configs[4]; the reference img2img '
+                            'rejects --plms, img2img.py:205-207)'),
+}
 
 
-def build_gpu_model(device, seed=0, vae_kind='hip'):
+def build_gpu_model(device, seed=0, vae_kind='hip', vae_parts=1):
     from stable_diffusion_amd import AutoencoderKLHIP, LatentDiffusionHIP, UNetModelHIP
     from stable_diffusion_amd.synthetic import SD_V1_UNET_KWARGS, SD_V1_VAE_DDCONFIG, randomize_, randomize_vae_
     unet = UNetModelHIP(**SD_V1_UNET_KWARGS)
     ld = LatentDiffusionHIP(unet).to(device).eval()
     randomize_(unet, seed)
     if vae_kind == 'hip':       # the first stage on the same gfx950 kernels (decoder part only)
-        vae = AutoencoderKLHIP(SD_V1_VAE_DDCONFIG, None, 4, parts=1).to(device).eval()
+        vae = AutoencoderKLHIP(SD_V1_VAE_DDCONFIG, None, 4, parts=vae_parts).to(device).eval()
         randomize_vae_(vae, seed)
     else:                       # A/B: the decoder on stock PyTorch-ROCm (fp16 autocast), what north_star started from
         from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
@@ -67,9 +83,25 @@ def one_image(sampler, vae, c, uc, x_T, steps_plms=50, scale=7.5):
     return lat, decode(vae, lat)
 
 
-def vae_latency_ms(vae, device, iters=5):
+def one_image_ddim(sampler, vae, c, uc, x_T, steps=50, scale=7.5):
+    lat, _ = sampler.sample(S=steps, batch_size=1, shape=list(x_T.shape[1:]), conditioning=c, verbose=False,
+                            x_T=x_T, unconditional_guidance_scale=scale, unconditional_conditioning=uc, eta=0.0)
+    return lat, decode(vae, lat)
+
+
+def one_image_img2img(sampler, vae, c, uc, init_image, steps=50, strength=0.75, scale=5.0):
+    """scripts/img2img.py:229-262: encode_first_stage -> stochastic_encode(t_enc) -> decode(t_enc DDIM steps) -> decode_first_stage"""
+    z0 = vae.encode_first_stage(init_image)                       # get_first_stage_encoding(encode_first_stage(x)): 0.18215 * sample
+    sampler.make_schedule(ddim_num_steps=steps, ddim_eta=0.0, verbose=False)
+    t_enc = int(strength * steps)
+    z_enc = sampler.stochastic_encode(z0, torch.tensor([t_enc] * z0.shape[0], device=z0.device))
+    lat = sampler.decode(z_enc, c, t_enc, unconditional_guidance_scale=scale, unconditional_conditioning=uc)
+    return lat, decode(vae, lat)
+
+
+def vae_latency_ms(vae, device, iters=5, H=64):
     g = torch.Generator(device='cpu').manual_seed(4)
-    lat = (torch.randn(1, 4, 64, 64, generator=g) * 0.9).to(device)
+    lat = (torch.randn(1, 4, H, H, generator=g) * 0.9).to(device)
     decode(vae, lat)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -119,7 +151,7 @@ def offline_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic_r01.json);
     PMC counters cannot be collected inside this process, so `roofline.traffic` is read from that committed pass."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r01.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r02.json')))
         k = d['kernels'].get(kernel_class)
         if k:
             return {'gbytes_per_launch': round((k['fetch_mb_x2'] + k['write_mb']) / 1e3, 4), 'source': d['source'],
@@ -219,9 +251,14 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--vae', choices=['hip', 'torch'], default='hip', help='first-stage decode: libsdmi (default) or PyTorch-ROCm')
+    ap.add_argument('--workload', choices=sorted(WORKLOADS), default='txt2img512',
+                    help='txt2img512 = BASELINE.json configs[1] (the headline metric, default); txt2img768 = configs[3]; '
+                         'img2img512 = configs[4]')
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    LAT = wl['latent']
 
-    from stable_diffusion_amd import PLMSSamplerHIP
+    from stable_diffusion_amd import DDIMSamplerHIP, PLMSSamplerHIP
     from stable_diffusion_amd import dist as sd_dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
@@ -231,14 +268,17 @@ def main():
     device = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
-    ld, unet, vae = build_gpu_model(device, vae_kind=args.vae)
-    sampler = PLMSSamplerHIP(ld)
+    ld, unet, vae = build_gpu_model(device, vae_kind=args.vae, vae_parts=wl['vae_parts'])
+    sampler = PLMSSamplerHIP(ld) if wl['sampler'] == 'plms' else DDIMSamplerHIP(ld)
     # synthetic conditioning / start codes; the seed depends on the GLOBAL prompt index only
     def inputs(step):
         gidx = step * world + rank
         g = torch.Generator(device='cpu').manual_seed(1000 + gidx)
         c = (0.1 * torch.randn(1, 77, 768, generator=g)).to(device)
-        x_T = torch.randn(1, 4, 64, 64, generator=g).to(device)
+        if wl['sampler'] == 'img2img':       # a synthetic init image in [-1, 1] (img2img.py:49-60 load_img)
+            x_T = (torch.rand(1, 3, LAT * 8, LAT * 8, generator=g) * 2.0 - 1.0).to(device)
+        else:
+            x_T = torch.randn(1, 4, LAT, LAT, generator=g).to(device)
         return c, x_T
     guc = torch.Generator(device='cpu').manual_seed(2)
     uc = (0.1 * torch.randn(1, 77, 768, generator=guc)).to(device)
@@ -247,51 +287,74 @@ def main():
         c, x_T = inputs(step)
         return c, uc, x_T
 
-    elapsed, lat, img, allz = timed_steps(lambda step: one_image(sampler, vae, *inputs_for(step)), args.steps, args.warmup,
-                                          world, rank, device)
+    if wl['sampler'] == 'plms':
+        step_fn = lambda step: one_image(sampler, vae, *inputs_for(step), steps_plms=wl['steps'], scale=wl['scale'])
+    elif wl['sampler'] == 'ddim':
+        step_fn = lambda step: one_image_ddim(sampler, vae, *inputs_for(step), steps=wl['steps'], scale=wl['scale'])
+    else:
+        step_fn = lambda step: one_image_img2img(sampler, vae, *inputs_for(step), steps=wl['steps'],
+                                                 strength=wl['strength'], scale=wl['scale'])
+    elapsed, lat, img, allz = timed_steps(step_fn, args.steps, args.warmup, world, rank, device)
     assert torch.isfinite(img).all() and torch.isfinite(allz).all()
 
     out = None
     if rank == 0:
         n_images = args.steps * world
         out = {
-            'metric': '512x512 images/sec, SD-v1-4 50-step PLMS CFG=7.5',
+            'metric': wl['metric'],
             'value': n_images / elapsed, 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
             'warmup': args.warmup, 'ms_per_step': elapsed / args.steps * 1e3, 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
-            'config': {'workload': 'SD-v1-4 UNet (859.5M params, random init), latent 4x64x64 (512x512), 50 PLMS steps = '
-                                   '51 UNet calls at CFG batch 2, scale 7.5, 1 prompt per GPU per step, + VAE decode ' +
+            'config': {'workload': f'{args.workload}: SD-v1-4 UNet (859.5M params, random init), ' + wl['desc'] +
+                                   ', 1 prompt per GPU per step, + VAE decode ' +
                                    ('(libsdmi AutoencoderKLHIP)' if args.vae == 'hip' else '(PyTorch-ROCm fp16 autocast)'),
                        'global_batch': world, 'parallelism': f'dp{world} (one prompt per GPU, latents all_gather)'},
         }
         if world == 1:
-            ms = unet_latency_ms(unet, device)
+            ms = unet_latency_ms(unet, device, H=LAT, W=LAT)
             out['unet_ms_per_call'] = ms
-            out['unet_tflops'] = UNET_GFLOP_64 / ms
-            out['vae_decode_ms'] = vae_latency_ms(vae, device)
+            out['unet_calls_per_image'] = wl['calls']
+            out['unet_tflops'] = UNET_GFLOP[LAT] / ms
+            out['vae_decode_ms'] = vae_latency_ms(vae, device, H=LAT)
             if not args.no_roofline:
-                table = profile_unet(unet, device)
+                table = profile_unet(unet, device, H=LAT, W=LAT)
                 table.sort(key=lambda r: -r['ms'])
-                dom = table[0]
+                # The implicit-GEMM kernel is ONE template (csrc/igemm.hip) launched in several tile instantiations
+                # chosen per shape by the tuning table: the dominant kernel is that family; its instantiations are listed.
+                fam = [r for r in table if r['name'].startswith('igemm')]
+                dom = {'name': 'igemm_kernel<BM,BN,waves,stages,kind> (all instantiations)',
+                       'launches': sum(r['launches'] for r in fam), 'ms': sum(r['ms'] for r in fam),
+                       'flops': sum(r['flops'] for r in fam), 'bytes': sum(r['bytes'] for r in fam)}
+                top = fam[0]
                 mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'attn'))]
-                ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12 if dom['flops'] > 0 else None
+                ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+                cls = lambda r: {'name': r['name'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
+                                 'tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if r['flops'] else None,
+                                 'gbs': round(r['bytes'] / (r['ms'] * 1e-3) / 1e9, 1)}
                 out['roofline'] = {
                     'bound': 'mfma', 'kernel': dom['name'], 'launches_per_unet_call': dom['launches'],
                     'avg_launch_ms': dom['ms'] / dom['launches'],
-                    'achieved': ach, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-                    'frac': (ach / MFMA_PEAK_TFLOPS) if ach else None,
-                    # HBM bytes per launch of this kernel class from the committed rocprofv3 PMC passes over the same
-                    # UNet call (separate FETCH_SIZE / WRITE_SIZE passes cannot run inside this process); null if absent
-                    'traffic': (lambda t: t['gbytes_per_launch'] * 1e9 if t else None)(offline_traffic(dom['name'])),
-                    'traffic_unit': 'bytes/launch', 'traffic_offline': offline_traffic(dom['name']),
+                    'achieved': ach, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_TFLOPS,
+                    'share_of_unet_call': dom['ms'] / sum(r['ms'] for r in table),
+                    'top_instantiation': dict(cls(top), frac=round(top['flops'] / (top['ms'] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)),
+                    # HBM bytes per launch from the committed rocprofv3 PMC passes over the same UNet call (separate
+                    # FETCH_SIZE / WRITE_SIZE passes cannot run inside this process); null if absent
+                    'traffic': (lambda t: t['gbytes_per_launch'] * 1e9 if t else None)(offline_traffic('igemm_family')),
+                    'traffic_unit': 'bytes/launch', 'traffic_offline': offline_traffic('igemm_family'),
                     'algorithmic_gbytes_per_launch': dom['bytes'] / dom['launches'] / 1e9,
-                    'per_class': [{'name': r['name'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
-                                   'tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if r['flops'] else None,
-                                   'gbs': round(r['bytes'] / (r['ms'] * 1e-3) / 1e9, 1)} for r in table],
+                    'per_class': [cls(r) for r in table],
                     'mfma_classes_tflops': sum(r['flops'] for r in mfma) / (sum(r['ms'] for r in mfma) * 1e-3) / 1e12
                     if mfma else None,
                 }
-            if not args.no_cpu_baseline:
+                # second entry: the dominant HBM-bound kernel class (norms / reduce / casts), against the HBM peak
+                hbm = [r for r in table if not r['name'].startswith(('igemm', 'attn'))]
+                if hbm:
+                    h = hbm[0]
+                    gbs = h['bytes'] / (h['ms'] * 1e-3) / 1e9
+                    out['roofline_hbm'] = {'bound': 'hbm', 'kernel': h['name'], 'launches_per_unet_call': h['launches'],
+                                           'avg_launch_ms': h['ms'] / h['launches'], 'achieved': gbs, 'peak': HBM_PEAK_GBS,
+                                           'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None}
+            if not args.no_cpu_baseline and args.workload == 'txt2img512':     # the CPU comparator is quoted on the headline config
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
     if world > 1:

@@ -40,7 +40,8 @@ class IGemmDesc(C.Structure):
                 ('seg_dst', c_ptr * 3), ('seg_kind', C.c_int32 * 3),
                 ('heads', C.c_int32), ('dh', C.c_int32), ('ntok', C.c_int32), ('ntok_pad', C.c_int32),
                 ('segC', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', c_ptr), ('splitk_ws_floats', C.c_int64),
-                ('tile', C.c_int32), ('dma', C.c_int32), ('asym_pad', C.c_int32)]
+                ('tile', C.c_int32), ('dma', C.c_int32), ('asym_pad', C.c_int32),
+                ('gn_n', C.c_int32), ('gn_acc', c_ptr * 2), ('gn_cpg', C.c_int32 * 2), ('gn_cbase', C.c_int32 * 2)]
 
 
 _SIGS = {

@@ -88,6 +88,13 @@ struct IGemmParams {
   int splitk = 1;                                      // 1 none, 0 auto, >1 forced
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
+  // optional (plain mode): GroupNorm(32) statistics of the finished output for up to two consuming GroupNorms -- the
+  // output's channels are channels [gn_cbase, gn_cbase + N) of that GroupNorm's (possibly concatenated) input with
+  // gn_cpg channels per group; gn_acc = its accumulator region (GroupNormParams::acc).  Needs Hout*Wout % 32 == 0.
+  int gn_n = 0;
+  long long* gn_acc[2] = {nullptr, nullptr};
+  int gn_cpg[2] = {0, 0}, gn_cbase[2] = {0, 0};
+  unsigned long long gn_magic[2] = {0, 0};             // ceil(2^40 / gn_cpg), filled by the launcher
   // filled by the launcher: ceil(2^40 / (Hout*Wout)) and ceil(2^40 / Wout) for the kernel's division-free row split
   unsigned long long magic_hw = 0, magic_w = 0;
 };
@@ -145,6 +152,7 @@ struct GroupNormParams {
   const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-5f;
   int silu = 0;
   int stats_only = 0;          // 1: only compute {mean, rstd} (consumed by conv3gn via gn_stats_ptr)
+  int skip_stats = 0;          // 1: the accumulators were already filled by the producing GEMM epilogues (IGemmParams::gn_*)
   f16* out_f16 = nullptr;      // [B*HW][C] normalised (+SiLU)
   float* out_f32 = nullptr;    // same in fp32 (used by the output head)
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)

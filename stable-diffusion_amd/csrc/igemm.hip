@@ -426,6 +426,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
               const float v = acc[i][j][r] + colv[j] + resv[r][j];
+              acc[i][j][r] = v;                       // final value, kept for the GroupNorm statistics below
               if (p.out_f32) p.out_f32[ro + j * 32] = v;
               if (p.out_f16) p.out_f16[ro + j * 32] = (f16)v;
               if (p.out_lo) p.out_lo[ro + j * 32] = (f16)(v - (float)(f16)v);
@@ -458,12 +459,62 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
               v += bias_v[j];
               if (rv) v += rv[n];
               if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+              acc[i][j][r] = v;
               if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
               if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
               if (p.out_lo) p.out_lo[(size_t)m * p.ldo + n] = (f16)(v - (float)(f16)v);
             }
           }
         }
+      }
+    }
+    // ---- GroupNorm statistics of the finished output, for the GroupNorm(s) that will read it (up to two: the next
+    // layer's, and the skip-concat's of an output block): {sum, sum of squares} per (sample, group) of this tile, added as
+    // fixed-point int64 to the consumer's accumulators -- the same words norm.hip's statistics kernel fills, so that
+    // kernel (one launch per GroupNorm) is not needed.  Integer atomics are associative: bit-reproducible.
+    // Needs Hout*Wout % 32 == 0 (a 32-row MFMA tile lies inside one sample); the executor checks it.
+    if (p.gn_n > 0 && !atomic) {
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + l31;
+        const bool nvalid = n < p.N;
+        auto flush = [&](int b, float s1, float s2, int slot) {
+          if (!nvalid) { s1 = 0.f; s2 = 0.f; }
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);         // the two half-waves hold disjoint rows of a column
+          for (int t = 0; t < p.gn_n; ++t) {
+            const int gid = nvalid ? fast_div(p.gn_cbase[t] + n, p.gn_magic[t]) : -1;
+            float a1 = s1, a2 = s2;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {                   // segmented sum over runs of equal group id
+              const float t1 = __shfl_down(a1, off, 32), t2 = __shfl_down(a2, off, 32);
+              const int tg = __shfl_down(gid, off, 32);
+              if (l31 + off < 32 && tg == gid) { a1 += t1; a2 += t2; }
+            }
+            const int gprev = __shfl_up(gid, 1, 32);
+            if (lg == 0 && gid >= 0 && (l31 == 0 || gprev != gid)) {
+              unsigned long long* dst = (unsigned long long*)p.gn_acc[t] + ((size_t)(b * 32 + gid) * GN_SLOTS + slot) * GN_WORDS;
+              gn_acc_add(dst, a1);
+              gn_acc_add(dst + 2, a2);
+            }
+          }
+        };
+        float s1 = 0.f, s2 = 0.f;
+        int bcur = -1, slot = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mt = mw + i * 32;                  // wave-uniform
+          if (mt < p.M) {
+            const int bi = mt / HWout;
+            if (bcur >= 0 && bi != bcur) { flush(bcur, s1, s2, slot); s1 = 0.f; s2 = 0.f; }
+            bcur = bi; slot = ((mt >> 5) + j) & (GN_SLOTS - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              if (m < p.M) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+            }
+          }
+        }
+        if (bcur >= 0) flush(bcur, s1, s2, slot);
       }
     }
   } else if (p.mode == EPI_GEGLU) {
@@ -566,30 +617,74 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 }
 
 // out = sum_s slab[s] + bias + rowvec[batch] + residual   (fixed summation order -> deterministic)
+// (+ the GroupNorm statistics of the result for its consumers, as in the GEMM epilogue: per block, the {sum, sumsq} of
+// every (sample, group) it touches are collected as fixed-point int64 in LDS -- integer adds, order independent -- and
+// then added to the global accumulators with one atomic set per non-empty entry)
 __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int nsplit) {
+  __shared__ unsigned long long s_gn[2][2][32][GN_WORDS];     // [target][sample within the block: first / next][group]
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int nq = p.N / 4;
-  if (idx >= (int64_t)p.M * nq) return;
-  const int m = (int)(idx / nq);
-  const int n = (int)(idx - (int64_t)m * nq) * 4;
-  const size_t slab_sz = (size_t)p.M * p.N;
-  const float* src = p.splitk_ws + (size_t)m * p.N + n;
-  f32x4 part[16];
+  const int HW = p.Hout * p.Wout;
+  const bool gn = p.gn_n > 0;
+  if (gn) {
+    for (int i = threadIdx.x; i < 2 * 2 * 32 * GN_WORDS; i += 256) (&s_gn[0][0][0][0])[i] = 0ull;
+    __syncthreads();
+  }
+  const bool live = idx < (int64_t)p.M * nq;
+  const int m = live ? (int)(idx / nq) : 0;
+  const int n = live ? (int)(idx - (int64_t)m * nq) * 4 : 0;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (live) {
+    const size_t slab_sz = (size_t)p.M * p.N;
+    const float* src = p.splitk_ws + (size_t)m * p.N + n;
+    f32x4 part[16];
 #pragma unroll
-  for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0, 0, 0, 0};
-  f32x4 v = part[0];
+    for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0, 0, 0, 0};
+    v = part[0];
 #pragma unroll
-  for (int s = 1; s < 16; ++s) v += part[s];       // fixed order; absent splits add +0
-  if (p.bias) v += *(const f32x4*)(p.bias + n);
-  if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / (p.Hout * p.Wout)) * p.ld_rowvec + n);
-  if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
-  if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
-  if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-  if (p.out_lo) {
-    f16x4 lo;
+    for (int s = 1; s < 16; ++s) v += part[s];       // fixed order; absent splits add +0
+    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / HW) * p.ld_rowvec + n);
+    if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+    if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
+    if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    if (p.out_lo) {
+      f16x4 lo;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) lo[j] = (f16)(v[j] - (float)(f16)v[j]);
-    *(f16x4*)(p.out_lo + (size_t)m * p.ldo + n) = lo;
+      for (int j = 0; j < 4; ++j) lo[j] = (f16)(v[j] - (float)(f16)v[j]);
+      *(f16x4*)(p.out_lo + (size_t)m * p.ldo + n) = lo;
+    }
+  }
+  if (gn) {
+    // the block covers 1024 consecutive elements = at most 1024 / N + 1 rows: they lie in at most two samples (checked by
+    // the launcher: HW >= that many rows)
+    const int b0 = (int)(((int64_t)blockIdx.x * blockDim.x) / nq) / HW;
+    if (live) {
+      const int bl = m / HW - b0;
+      for (int t = 0; t < p.gn_n; ++t) {
+        const int c = p.gn_cbase[t] + n;
+        const int g0 = fast_div(c, p.gn_magic[t]), g1 = fast_div(c + 3, p.gn_magic[t]);
+        const int split = (g0 + 1) * p.gn_cpg[t] - c;              // first of the 4 channels that belongs to g1
+        float a1 = 0.f, a2 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          if (j < split) { a1 += v[j]; a2 += v[j] * v[j]; } else { c1 += v[j]; c2 += v[j] * v[j]; }
+        }
+        gn_acc_add(&s_gn[t][bl][g0][0], a1);
+        gn_acc_add(&s_gn[t][bl][g0][2], a2);
+        if (g1 != g0) { gn_acc_add(&s_gn[t][bl][g1][0], c1); gn_acc_add(&s_gn[t][bl][g1][2], c2); }
+      }
+    }
+    __syncthreads();
+    const int slot = blockIdx.x & (GN_SLOTS - 1);
+    for (int e = threadIdx.x; e < 2 * 2 * 32 * GN_WORDS; e += 256) {
+      const unsigned long long w = (&s_gn[0][0][0][0])[e];
+      if (w == 0ull) continue;
+      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, bl = (e / (GN_WORDS * 32)) % 2, t = e / (GN_WORDS * 32 * 2);
+      if (t >= p.gn_n || b0 + bl >= p.B) continue;
+      unsigned long long* dst = (unsigned long long*)p.gn_acc[t] + ((size_t)((b0 + bl) * 32 + g) * GN_SLOTS + slot) * GN_WORDS + word;
+      atomicAdd(dst, w);
+    }
   }
 }
 
@@ -640,6 +735,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   q.splitk = nsplit;
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
+  for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
   static const int by_shape = env_int("SDMI_PROF_SHAPES", 0);
   std::string pname = std::string("igemm_") + std::to_string(BM) + "x" + std::to_string(BN) + "w" +
@@ -911,6 +1007,12 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && p.ldo == p.N && p.N % 4 == 0 && p.N <= 2560 && p.ln_gamma && p.ln_beta,
                "LayerNorm post-op needs plain mode, an fp32 output with ldo == N <= 2560, gamma and beta");
   if (p.out_lo) SDMI_CHECK(p.mode == EPI_PLAIN && p.ldo % 4 == 0, "out_lo needs plain mode");
+  if (p.gn_n) {
+    SDMI_CHECK(p.mode == EPI_PLAIN && p.gn_n <= 2 && (p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need plain mode and Hout*Wout % 32 == 0");
+    SDMI_CHECK(p.N % 4 == 0 && (int64_t)p.Hout * p.Wout >= 1024 / p.N + 2, "GroupNorm statistics: N % 4 == 0, and a reduce block within two samples");
+    for (int t = 0; t < p.gn_n; ++t)
+      SDMI_CHECK(p.gn_acc[t] && p.gn_cpg[t] >= 2 && (p.gn_cbase[t] + p.N + p.gn_cpg[t] - 1) / p.gn_cpg[t] <= 32, "bad GroupNorm statistics target");
+  }
   if (p.mode == EPI_HEADS) SDMI_CHECK(p.segC > 0 && p.dh > 0 && p.N % p.segC == 0 && p.N / p.segC <= 3, "bad head scatter");
 
   SDMI_CHECK((int64_t)p.B * p.Hin * p.Win * p.lda0 * 2 + (int64_t)(p.Win + 1) * p.lda0 * 2 < ((int64_t)1 << 31) - 65536 &&

@@ -221,7 +221,7 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int nchunk = cdiv(p.HW, chunk_px);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
-  hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
+  if (!p.skip_stats) hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
   if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
     const int64_t quads = (int64_t)p.HW * (C / 4);
     static const int64_t u4_from = getenv("SDMI_GN_APPLY_U4_QUADS") ? atoll(getenv("SDMI_GN_APPLY_U4_QUADS")) : ((int64_t)1 << 20);   // A/B knob

@@ -45,6 +45,7 @@ int UNet::build(const sdmi_unet_cfg& c) {
   te_ = 4 * mc;
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_FUSE_GN_CONV")) fuse_gn_conv_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_FUSE_GN_STATS")) fuse_gn_stats_ = atoi(e) != 0;
   const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
 
   auto add_res = [&](const std::string& p, int cin, int cout) {
@@ -439,8 +440,8 @@ struct Fwd : FwdBase {
     f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
     f16* raw_lo = (Cin != Cout && precise_1x1) ? S<f16>((size_t)M * Cin) : nullptr;
     float* h = S<float>((size_t)M * Cout);
-    Act out; out.p = P<float>((size_t)M * Cout); out.C = Cout; out.H = H; out.W = W;
-    Act hact; hact.p = h; hact.C = Cout; hact.H = H; hact.W = W;
+    Act out = make_act(P<float>((size_t)M * Cout), Cout, H, W, !fused);
+    Act hact = make_act(h, Cout, H, W, !fused);
     if (fused) {
       gn_stats_only(x0, x1, 1e-5f, raw, raw_lo, L.f32[0], L.f32[1]);
       Conv3GnParams c;
@@ -455,6 +456,7 @@ struct Fwd : FwdBase {
       IGemmParams p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
       p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = u->emb_total_;
       p.out_f32 = h; p.ldo = Cout;
+      attach_gn_targets(p, hact);          // statistics of out_layers' GroupNorm come out of this epilogue
       gemm(p);
     }
     const float* residual = x0.p;
@@ -476,6 +478,7 @@ struct Fwd : FwdBase {
       groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
       IGemmParams p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
       p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
+      attach_gn_targets(p, out);           // ... and those of the GroupNorm(s) that read this block's output
       gemm(p);
     }
     scratch.off = mark;
@@ -578,10 +581,12 @@ struct Fwd : FwdBase {
         gemm(p);
       }
     }
-    Act out; out.p = P<float>((size_t)M * C); out.C = C; out.H = H; out.W = W;
+    Act out = make_act(P<float>((size_t)M * C), C, H, W, true);
     {
       IGemmParams p = dense1x1(ln, xn_lo, M, C, L.w16[1], C, N);
+      p.Hout = H * W;                       // (dense: rows per sample)
       p.bias = L.f32[3]; p.residual = x.p; p.ldr = C; p.out_f32 = out.p; p.ldo = C;
+      attach_gn_targets(p, out);
       gemm(p);
     }
     scratch.off = mark;
@@ -601,9 +606,10 @@ struct Fwd : FwdBase {
     const size_t mark = scratch.off;
     f16* x16 = S<f16>((size_t)B * Hin * Win * C);
     if (!dry && !rc) ok(launch_cast_f16(x.p, x16, nullptr, (int64_t)B * Hin * Win * C, s));
-    Act out; out.p = P<float>((size_t)B * Hout * Wout * C); out.C = L.cout; out.H = Hout; out.W = Wout;
+    Act out = make_act(P<float>((size_t)B * Hout * Wout * C), L.cout, Hout, Wout, true);
     IGemmParams p = conv3(x16, C, Hin, Win, Hout, Wout, up ? 1 : 2, up ? 1 : 0, L.w16[0], L.cout);
     p.bias = L.f32[0]; p.out_f32 = out.p; p.ldo = L.cout;
+    attach_gn_targets(p, out);
     gemm(p);
     scratch.off = mark;
     return out;
@@ -657,6 +663,9 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     const bool d = (pass == 0) ? true : false;
     if (pass == 1 && dry) break;
     f.dry = d; f.rc = 0;
+    f.n_acts = 0;
+    f.plan = fuse_gn_stats_ ? &gn_plan_ : nullptr;
+    if (d) gn_plan_.clear();
     f.persist = Arena(); f.scratch = Arena();
     f.persist.dry = f.scratch.dry = d;
     if (!d) {
@@ -701,7 +710,7 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       Act h;
       {
         Layer& L = input_blocks_[0][0];
-        h.p = f.P<float>((size_t)B * H * W * mc); h.C = mc; h.H = H; h.W = W;
+        h = f.make_act(f.P<float>((size_t)B * H * W * mc), mc, H, W, false);     // conv_in is not an igemm: no fused statistics
         if (!d) { int r = launch_conv_in(x, L.w32[0], L.f32[0], h.p, B, cfg_.in_channels, H, W, mc, stream); if (r) return r; }
         hs.push_back(h);
       }

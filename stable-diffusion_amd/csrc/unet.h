@@ -23,7 +23,18 @@ struct Arena {
   }
 };
 
-struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; };
+// an fp32 NHWC activation.  `id` / `stats` serve the GroupNorm-statistics fusion: an activation produced by an igemm
+// epilogue (or its split-K reduce) can have the {sum, sumsq} of its consumers' GroupNorm groups accumulated there.
+struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; int id = -1; bool stats = false; };
+
+// one GroupNorm that will read an activation: accumulator region index, the activation's first channel inside that
+// GroupNorm's (concatenated) input, channels per group
+struct GnTarget { int gn_idx = 0, cbase = 0, cpg = 0; };
+struct GnPlan {                       // built by the dry pass of a forward, consumed by the real pass
+  std::vector<std::vector<GnTarget>> targets;    // per activation id
+  std::vector<char> fused;                       // per GroupNorm call: statistics come from the producers' epilogues
+  void clear() { targets.clear(); fused.clear(); }
+};
 
 // state and helpers shared by the executors (UNet forward, first-stage encode / decode): arenas, GroupNorm accumulator
 // regions, split-K slabs and the igemm / GroupNorm launch wrappers
@@ -36,6 +47,27 @@ struct FwdBase {
   int gn_calls = 0;
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   int rc = 0;
+  GnPlan* plan = nullptr;         // null: GroupNorm statistics always by the statistics kernel (first stage, text encoder)
+  int n_acts = 0;
+
+  // register an activation; `by_igemm`: its producer is an igemm epilogue / split-K reduce that can emit statistics
+  Act make_act(float* ptr, int C, int H, int W, bool by_igemm) {
+    Act a; a.p = ptr; a.C = C; a.H = H; a.W = W; a.id = n_acts++;
+    a.stats = by_igemm && plan != nullptr && (H * W) % 32 == 0 && H * W >= 1024 / C + 2 && C % 4 == 0 && C / 32 >= 2;
+    if (plan && dry && (int)plan->targets.size() < n_acts) plan->targets.resize(n_acts);
+    return a;
+  }
+  // attach the statistics targets of activation `a` (all GroupNorms that will read it and rely on fused statistics)
+  void attach_gn_targets(IGemmParams& p, const Act& a) {
+    p.gn_n = 0;
+    if (dry || !plan || !a.stats || a.id < 0 || a.id >= (int)plan->targets.size()) return;
+    for (const GnTarget& t : plan->targets[a.id]) {
+      if (p.gn_n >= 2) { ok(fail("internal: more than two GroupNorm consumers of one activation")); return; }
+      p.gn_acc[p.gn_n] = gn_acc + (size_t)t.gn_idx * gn_acc_words(B);
+      p.gn_cpg[p.gn_n] = t.cpg; p.gn_cbase[p.gn_n] = t.cbase;
+      ++p.gn_n;
+    }
+  }
 
   template <class T> T* P(size_t n) { return (T*)persist.alloc(n * sizeof(T)); }
   template <class T> T* S(size_t n) { return (T*)scratch.alloc(n * sizeof(T)); }
@@ -92,7 +124,24 @@ struct FwdBase {
     g.x0 = x0.p; g.c0 = x0.C;
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
     g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
-    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo; g.acc = next_gn_acc();
+    g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo;
+    const int idx = gn_calls;
+    g.acc = next_gn_acc();
+    if (plan) {
+      const int cpg = (g.c0 + g.c1) / 32;
+      if (dry) {
+        // statistics are fused iff EVERY source of this GroupNorm comes from a statistics-capable producer
+        const bool f = x0.stats && (!x1 || x1->stats) && x0.id >= 0 && (!x1 || x1->id >= 0);
+        if ((int)plan->fused.size() <= idx) plan->fused.resize(idx + 1, 0);
+        plan->fused[idx] = f ? 1 : 0;
+        if (f) {
+          plan->targets[x0.id].push_back({idx, 0, cpg});
+          if (x1) plan->targets[x1->id].push_back({idx, g.c0, cpg});
+        }
+      } else {
+        g.skip_stats = (idx < (int)plan->fused.size() && plan->fused[idx]) ? 1 : 0;
+      }
+    }
     if (!dry && !rc) ok(launch_groupnorm(g, s));
   }
 };
@@ -175,6 +224,8 @@ class UNet {
   int dev_alloc(void** dst, size_t bytes);
   size_t slot_bytes(const WeightSlot& s) const;
   int ensure_ctx_cache(int B, int Lctx);
+  GnPlan gn_plan_;           // GroupNorm-statistics fusion plan of the current forward (rebuilt by its dry pass)
+  bool fuse_gn_stats_ = true;   // SDMI_FUSE_GN_STATS=0: every GroupNorm runs its own statistics kernel (A/B, debugging)
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
   std::vector<Layer> middle_;

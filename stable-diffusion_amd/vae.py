@@ -194,7 +194,8 @@ class AutoencoderKLHIP(nn.Module):
             need = fn(self._handle.h, B, H, W)
             if need <= 0:
                 _lib.check(-1)
-            self._ws.clear()          # one live workspace: decode and encode shapes rarely alternate
+            for k in [k for k in self._ws if k[0] == kind]:     # one live workspace per direction (img2img alternates
+                del self._ws[k]                                  # encode and decode for every image)
             self._ws[key] = torch.empty(int(need), dtype=torch.uint8, device=device)
         return self._ws[key]
 

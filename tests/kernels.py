@@ -43,7 +43,7 @@ def cast_f16(x, want_lo=False):
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
           residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None,
-          asym_pad=0):
+          asym_pad=0, gn=None):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
     d = _lib.IGemmDesc()
     d.a0 = a0.data_ptr(); d.c0 = a0.shape[1]; d.lda0 = a0.stride(0)
@@ -67,12 +67,24 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
         d.heads, d.dh, d.ntok, d.ntok_pad, d.segC = heads['heads'], heads['dh'], heads['ntok'], heads['ntok_pad'], heads['segC']
     d.splitk, d.tile, d.dma = splitk, tile, dma
     d.asym_pad = asym_pad
+    if gn:      # [(acc int64 tensor [B,32,8,4] (zeroed), cpg, cbase)]
+        d.gn_n = len(gn)
+        for i, (acc, cpg, cbase) in enumerate(gn):
+            d.gn_acc[i] = acc.data_ptr(); d.gn_cpg[i] = cpg; d.gn_cbase[i] = cbase
     ws = None
     if splitk != 1:
         M = B * Hout * Wout
         ws = torch.empty((16 * M * N,), dtype=torch.float32, device=a0.device)
         d.splitk_ws = ws.data_ptr(); d.splitk_ws_floats = ws.numel()
     _lib.check(_lib.load().sdmi_k_igemm(C.byref(d), _s()))
+
+
+def gn_acc_sums(acc):
+    """accumulator words [B, 32, 8 slots, 4] int64 -> (sum, sumsq) [B, 32] float64"""
+    a = acc.cpu().to(torch.float64)
+    s = (a[..., 0] + a[..., 1] / 2.0 ** 40).sum(-1)
+    ss = (a[..., 2] + a[..., 3] / 2.0 ** 40).sum(-1)
+    return s, ss
 
 
 def attention(q, k, vt, heads, nkv, scale):

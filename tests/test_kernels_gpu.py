@@ -28,6 +28,8 @@ def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
 
 
+ALL_TILES = list(range(14))     # include/sdmi.h: sdmi_igemm_desc.tile
+
 CONV_CASES = [
     # name, B, Hin, Win, c0, c1, N, ksize, stride, up
     ('dense_masked', 2, 10, 10, 320, 0, 328, 1, 1, 0),
@@ -55,9 +57,6 @@ def _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up):
 
 
 @pytest.mark.parametrize('case', CONV_CASES, ids=[c[0] for c in CONV_CASES])
-ALL_TILES = list(range(14))     # include/sdmi.h: sdmi_igemm_desc.tile
-
-
 @pytest.mark.parametrize('tile', ALL_TILES)
 @pytest.mark.parametrize('dma', [0, 1])
 def test_igemm_conv(case, tile, dma):
@@ -113,6 +112,41 @@ def test_igemm_splitk_inplace_residual(splitk, tile):
     K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV), residual=out2, out_f32=out2, splitk=splitk, tile=tile)
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+@pytest.mark.parametrize('tile', [2, 5, 7, 8, 9, 12, 13])
+@pytest.mark.parametrize('splitk', [1, 3])
+@pytest.mark.parametrize('B,H,W,C,N', [(2, 8, 8, 128, 320), (3, 4, 8, 64, 200), (2, 16, 16, 64, 64)])
+def test_igemm_groupnorm_statistics(tile, splitk, B, H, W, C, N):
+    """GroupNorm(32) statistics of a conv output from the GEMM epilogue (split-K: from the reduce kernel): for the next
+    layer's GroupNorm over the output alone (cpg = N / 32 ... here N / 20 to land group borders inside MFMA tiles) and for
+    a skip-concat GroupNorm where the output is channels [cbase, cbase + N) (util.py:199-216, openaimodel.py:736)."""
+    g = _g(91)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(9 * C))
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(B * H * W, N, generator=g)
+    ref = _nhwc(_conv_ref(a, None, w, B, H, W, 3, 1, 0)) + bias[None] + resid        # [M, N]
+    cpg0 = N // 20 if N % 20 == 0 else N // 8
+    cbase1, cpg1 = 3 * cpg0 + 4, cpg0 + 4
+    acc0 = torch.zeros((B, 32, 8, 4), dtype=torch.int64, device=DEV)
+    acc1 = torch.zeros((B, 32, 8, 4), dtype=torch.int64, device=DEV)
+    out = torch.full((B * H * W, N), float('nan'), device=DEV)
+    K.igemm(a.to(DEV), K.pack_conv_weight(w.float().to(DEV)), N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV),
+            residual=resid.to(DEV), out_f32=out, splitk=splitk, tile=tile, gn=[(acc0, cpg0, 0), (acc1, cpg1, cbase1)])
+    torch.cuda.synchronize()
+    assert K.report(f'igemm+gn value tile{tile} k{splitk}', out, ref, 2e-4) < 2e-4
+    v = out.cpu().double().reshape(B, H * W, N)
+    for name, acc, cpg, cbase in (('next', acc0, cpg0, 0), ('concat', acc1, cpg1, cbase1)):
+        s, ss = K.gn_acc_sums(acc)
+        rs, rss = torch.zeros(B, 32, dtype=torch.float64), torch.zeros(B, 32, dtype=torch.float64)
+        for n in range(N):
+            gi = (cbase + n) // cpg
+            rs[:, gi] += v[:, :, n].sum(1)
+            rss[:, gi] += (v[:, :, n] ** 2).sum(1)
+        e1, e2 = (s - rs).abs().max().item(), ((ss - rss).abs() / (1.0 + rss)).max().item()
+        print(f'[gn-stats {name} tile{tile} k{splitk}] |sum err| {e1:.3e} rel sumsq err {e2:.3e}', flush=True)
+        assert e1 < 2e-3 and e2 < 1e-5
 
 
 @pytest.mark.parametrize('B,H,W,C,N,splitk,tile', [(2, 16, 16, 1280, 1280, 4, 2), (2, 8, 8, 1280, 1280, 15, 2),
