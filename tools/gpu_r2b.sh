@@ -28,8 +28,8 @@ for f in glob.glob('gpurun_out/b_prof/**/*_results.db', recursive=True):
         out.write('rocprofv3 --kernel-trace --stats -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-roofline\n(2 images = 102 UNet calls + 2 first-stage decodes + 12 UNet calls / 6 decodes of the latency probes)\n')
         out.write(f'{"calls":>7s} {"total_ms":>10s} {"avg_us":>9s} {"pct":>6s}  kernel\n')
         for name,calls,total,avg,pct in rows[:70]:
-            out.write(f'{calls:7d} {total/1e6:10.3f} {avg/1e3:9.2f} {pct:6.2f}  {name[:150]}\n')
-        out.write(f'total kernel time {tot/1e6:.1f} ms\n')
+            out.write(f"{calls:7d} {total/1e3:10.3f} {avg:9.2f} {pct:6.2f}  {name[:150]}\n")
+        out.write(f'total kernel time {tot/1e3:.1f} ms\n')
     print(open('gpurun_out/b_kernel_stats.txt').read()[:3500])
 PY
 el done
