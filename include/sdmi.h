@@ -189,7 +189,8 @@ typedef struct sdmi_igemm_desc {
                                            F.pad(x,(0,1,0,1)) + conv(padding=0) of the VAE Downsample (model.py:72-76) */
   /* optional (mode 0, Hout*Wout % 32 == 0): GroupNorm(32) statistics of the output for up to two consuming GroupNorms
    * (util.py:199-216), accumulated by the epilogue / the split-K reduce into int64 fixed-point words
-   * gn_acc[t][B][32 groups][8 slots][4] = {sum int, sum frac * 2^40, sumsq int, sumsq frac * 2^40} (zero them first);
+   * gn_acc[t][B][32 groups][8 slots][16] (one 128-byte line per slot; words 0..3 = {sum int, sum frac * 2^40, sumsq int,
+   * sumsq frac * 2^40}; zero them first);
    * the output is channels [gn_cbase, gn_cbase + N) of that GroupNorm's input, gn_cpg channels per group */
   int32_t gn_n; void* gn_acc[2]; int32_t gn_cpg[2]; int32_t gn_cbase[2];
 } sdmi_igemm_desc;

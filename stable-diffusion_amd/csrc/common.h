@@ -158,7 +158,7 @@ struct GroupNormParams {
   f16* raw_f16 = nullptr;      // optional: un-normalised fp16 copy of cat(x0,x1) (A operand of the 1x1 skip conv)
   f16* out_lo = nullptr;       // optional: fp16(y - float(fp16(y)))   -- low half of a split-fp16 operand
   f16* raw_lo = nullptr;       // optional: same for the raw copy
-  // fixed-point statistics accumulators of THIS GroupNorm call: [B][32 groups][GN_SLOTS][GN_WORDS] int64, zero before
+  // fixed-point statistics accumulators of THIS GroupNorm call: [B][32 groups][GN_SLOTS][GN_STRIDE] int64 (GN_WORDS used), zero before
   // the launch.  Each of {sum, sumsq} is kept as an integer part and a 2^-40 fraction (two words), so the range is that
   // of an int64 and nothing can wrap.  Integer atomics are associative: the statistics are bit-reproducible without a
   // finalize pass or inter-block ordering; consumers fold the slots themselves (gn_fold in norm.hip).
@@ -167,7 +167,11 @@ struct GroupNormParams {
 constexpr int GN_SLOTS = 8;
 constexpr int GN_MAX_CALLS = 96;   // accumulator regions per UNet forward (SD v1 has 61 GroupNorms)
 constexpr int GN_WORDS = 4;         // {sum int, sum frac * 2^40, sumsq int, sumsq frac * 2^40}
-static inline int64_t gn_acc_words(int B) { return (int64_t)B * 32 * GN_SLOTS * GN_WORDS; }   // int64 words per GroupNorm call
+// words between two slot entries: every (sample, group, slot) entry owns a 128-byte line, so the atomic adds of one
+// GroupNorm spread over 512+ lines / all memory channels instead of queueing on 128 (measured: the adds, not the
+// arithmetic, were what the statistics cost)
+constexpr int GN_STRIDE = 16;
+static inline int64_t gn_acc_words(int B) { return (int64_t)B * 32 * GN_SLOTS * GN_STRIDE; }   // int64 words per GroupNorm call
 int launch_groupnorm(const GroupNormParams& p, hipStream_t stream);
 
 int launch_layernorm(const float* x, const float* gamma, const float* beta, f16* out, int M, int C, float eps,

@@ -76,7 +76,7 @@ __global__ void __launch_bounds__(256) conv3gn_kernel(const Conv3GnParams p, con
   __shared__ float s_tab[64];
   float* const s_stats = s_tab;
   {
-    const long long* src = p.acc + ((size_t)(b * 32 + (tid >> 3)) * GN_SLOTS + (tid & 7)) * GN_WORDS;
+    const long long* src = p.acc + ((size_t)(b * 32 + (tid >> 3)) * GN_SLOTS + (tid & 7)) * GN_STRIDE;
     long long s = src[0], sl = src[1], ss = src[2], ssl = src[3];
 #pragma unroll
     for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {

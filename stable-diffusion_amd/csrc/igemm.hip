@@ -471,14 +471,23 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     // ---- GroupNorm statistics of the finished output, for the GroupNorm(s) that will read it (up to two: the next
     // layer's, and the skip-concat's of an output block): {sum, sum of squares} per (sample, group) of this tile, added as
     // fixed-point int64 to the consumer's accumulators -- the same words norm.hip's statistics kernel fills, so that
-    // kernel (one launch per GroupNorm) is not needed.  Integer atomics are associative: bit-reproducible.
+    // kernel (one launch per GroupNorm) is not needed.  Integer adds are associative: bit-reproducible.  The waves of the
+    // block first combine in LDS (the tile buffers are free now), so the block issues ONE global atomic set per
+    // (sample, group) it touched: the global adds, not the arithmetic, are what statistics cost.
     // Needs Hout*Wout % 32 == 0 (a 32-row MFMA tile lies inside one sample); the executor checks it.
     if (p.gn_n > 0 && !atomic) {
+      constexpr int GNB = BM / 32;                        // samples a tile can touch (Hout*Wout >= 32)
+      unsigned long long* lacc = (unsigned long long*)smem;                  // [target][sample in tile][group][GN_WORDS]
+      static_assert(2 * GNB * 32 * GN_WORDS * 8 <= NS * STAGE_BYTES, "LDS too small for the statistics accumulators");
+      __syncthreads();                                    // every wave's LDS-DMA has landed (wait_vmcnt<0> above) and is unread
+      for (int e = tid; e < 2 * GNB * 32 * GN_WORDS; e += NT) lacc[e] = 0ull;
+      __syncthreads();
+      const int b_tile = m0 / HWout;
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int n = nw + j * 32 + l31;
         const bool nvalid = n < p.N;
-        auto flush = [&](int b, float s1, float s2, int slot) {
+        auto flush = [&](int b, float s1, float s2) {
           if (!nvalid) { s1 = 0.f; s2 = 0.f; }
           s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);         // the two half-waves hold disjoint rows of a column
           for (int t = 0; t < p.gn_n; ++t) {
@@ -492,21 +501,21 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
             }
             const int gprev = __shfl_up(gid, 1, 32);
             if (lg == 0 && gid >= 0 && (l31 == 0 || gprev != gid)) {
-              unsigned long long* dst = (unsigned long long*)p.gn_acc[t] + ((size_t)(b * 32 + gid) * GN_SLOTS + slot) * GN_WORDS;
+              unsigned long long* dst = lacc + ((size_t)(t * GNB + (b - b_tile)) * 32 + gid) * GN_WORDS;
               gn_acc_add(dst, a1);
               gn_acc_add(dst + 2, a2);
             }
           }
         };
         float s1 = 0.f, s2 = 0.f;
-        int bcur = -1, slot = 0;
+        int bcur = -1;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int mt = mw + i * 32;                  // wave-uniform
           if (mt < p.M) {
             const int bi = mt / HWout;
-            if (bcur >= 0 && bi != bcur) { flush(bcur, s1, s2, slot); s1 = 0.f; s2 = 0.f; }
-            bcur = bi; slot = ((mt >> 5) + j) & (GN_SLOTS - 1);
+            if (bcur >= 0 && bi != bcur) { flush(bcur, s1, s2); s1 = 0.f; s2 = 0.f; }
+            bcur = bi;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
@@ -514,7 +523,16 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
             }
           }
         }
-        if (bcur >= 0) flush(bcur, s1, s2, slot);
+        if (bcur >= 0) flush(bcur, s1, s2);
+      }
+      __syncthreads();
+      const int slot = (tile_m + tile_n) & (GN_SLOTS - 1);
+      for (int e = tid; e < p.gn_n * GNB * 32 * GN_WORDS; e += NT) {
+        const unsigned long long w = lacc[e];
+        if (w == 0ull) continue;
+        const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, bl = (e / (GN_WORDS * 32)) % GNB, t = e / (GN_WORDS * 32 * GNB);
+        if (b_tile + bl >= p.B) continue;
+        atomicAdd((unsigned long long*)p.gn_acc[t] + ((size_t)((b_tile + bl) * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
       }
     }
   } else if (p.mode == EPI_GEGLU) {
@@ -617,33 +635,43 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 }
 
 // out = sum_s slab[s] + bias + rowvec[batch] + residual   (fixed summation order -> deterministic)
-// (+ the GroupNorm statistics of the result for its consumers, as in the GEMM epilogue: per block, the {sum, sumsq} of
-// every (sample, group) it touches are collected as fixed-point int64 in LDS -- integer adds, order independent -- and
-// then added to the global accumulators with one atomic set per non-empty entry)
-__global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int nsplit) {
-  __shared__ unsigned long long s_gn[2][2][32][GN_WORDS];     // [target][sample within the block: first / next][group]
-  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int nq = p.N / 4;
+// A block owns a strip of 32 columns x `rows_per_block` rows (thread = one 16-byte quad of a row; 8 threads cover a
+// 128-byte line), walking the rows 32 at a time.  With GroupNorm statistics (see the GEMM epilogue): the strip lies inside
+// one sample (rows_per_block divides Hout*Wout) and touches at most 32 / cpg + 2 groups; the per-thread sums are combined
+// as fixed-point int64 in LDS (integer adds: order independent) and leave the block as one global atomic set per group.
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int nsplit, int rows_per_block) {
+  __shared__ unsigned long long s_gn[2][32][GN_WORDS];        // [target][group]
+  const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+  const int n = (blockIdx.x * 8 + tx) * 4;
+  const int row0 = blockIdx.y * rows_per_block;
   const int HW = p.Hout * p.Wout;
   const bool gn = p.gn_n > 0;
+  const bool ncol = n < p.N;
   if (gn) {
-    for (int i = threadIdx.x; i < 2 * 2 * 32 * GN_WORDS; i += 256) (&s_gn[0][0][0][0])[i] = 0ull;
+    for (int i = threadIdx.x; i < 2 * 32 * GN_WORDS; i += 256) (&s_gn[0][0][0])[i] = 0ull;
     __syncthreads();
   }
-  const bool live = idx < (int64_t)p.M * nq;
-  const int m = live ? (int)(idx / nq) : 0;
-  const int n = live ? (int)(idx - (int64_t)m * nq) * 4 : 0;
-  f32x4 v = {0.f, 0.f, 0.f, 0.f};
-  if (live) {
-    const size_t slab_sz = (size_t)p.M * p.N;
+  const size_t slab_sz = (size_t)p.M * p.N;
+  f32x4 biasv = {0.f, 0.f, 0.f, 0.f};
+  if (ncol && p.bias) biasv = *(const f32x4*)(p.bias + n);
+  float a1[2] = {0.f, 0.f}, a2[2] = {0.f, 0.f}, c1[2] = {0.f, 0.f}, c2[2] = {0.f, 0.f};
+  int g0[2] = {0, 0}, g1[2] = {0, 0}, gsplit[2] = {4, 4};
+  for (int t = 0; t < p.gn_n; ++t) {
+    const int c = p.gn_cbase[t] + n;
+    g0[t] = fast_div(c, p.gn_magic[t]); g1[t] = fast_div(c + 3, p.gn_magic[t]);
+    gsplit[t] = (g0[t] + 1) * p.gn_cpg[t] - c;                  // first of the 4 channels that belongs to g1
+  }
+  for (int r = ty; r < rows_per_block; r += 32) {
+    const int m = row0 + r;
+    if (!ncol || m >= p.M) continue;
     const float* src = p.splitk_ws + (size_t)m * p.N + n;
     f32x4 part[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0, 0, 0, 0};
-    v = part[0];
+    f32x4 v = part[0];
 #pragma unroll
     for (int s = 1; s < 16; ++s) v += part[s];       // fixed order; absent splits add +0
-    if (p.bias) v += *(const f32x4*)(p.bias + n);
+    v += biasv;
     if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / HW) * p.ld_rowvec + n);
     if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
     if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
@@ -654,36 +682,32 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
       for (int j = 0; j < 4; ++j) lo[j] = (f16)(v[j] - (float)(f16)v[j]);
       *(f16x4*)(p.out_lo + (size_t)m * p.ldo + n) = lo;
     }
-  }
-  if (gn) {
-    // the block covers 1024 consecutive elements = at most 1024 / N + 1 rows: they lie in at most two samples (checked by
-    // the launcher: HW >= that many rows)
-    const int b0 = (int)(((int64_t)blockIdx.x * blockDim.x) / nq) / HW;
-    if (live) {
-      const int bl = m / HW - b0;
-      for (int t = 0; t < p.gn_n; ++t) {
-        const int c = p.gn_cbase[t] + n;
-        const int g0 = fast_div(c, p.gn_magic[t]), g1 = fast_div(c + 3, p.gn_magic[t]);
-        const int split = (g0 + 1) * p.gn_cpg[t] - c;              // first of the 4 channels that belongs to g1
-        float a1 = 0.f, a2 = 0.f, c1 = 0.f, c2 = 0.f;
+    if (gn) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          if (j < split) { a1 += v[j]; a2 += v[j] * v[j]; } else { c1 += v[j]; c2 += v[j] * v[j]; }
+          if (j < gsplit[t]) { a1[t] += v[j]; a2[t] += v[j] * v[j]; } else { c1[t] += v[j]; c2[t] += v[j] * v[j]; }
         }
-        gn_acc_add(&s_gn[t][bl][g0][0], a1);
-        gn_acc_add(&s_gn[t][bl][g0][2], a2);
-        if (g1 != g0) { gn_acc_add(&s_gn[t][bl][g1][0], c1); gn_acc_add(&s_gn[t][bl][g1][2], c2); }
+      }
+    }
+  }
+  if (gn) {
+    if (ncol) {
+      for (int t = 0; t < p.gn_n; ++t) {
+        gn_acc_add(&s_gn[t][g0[t]][0], a1[t]);
+        gn_acc_add(&s_gn[t][g0[t]][2], a2[t]);
+        if (g1[t] != g0[t]) { gn_acc_add(&s_gn[t][g1[t]][0], c1[t]); gn_acc_add(&s_gn[t][g1[t]][2], c2[t]); }
       }
     }
     __syncthreads();
-    const int slot = blockIdx.x & (GN_SLOTS - 1);
-    for (int e = threadIdx.x; e < 2 * 2 * 32 * GN_WORDS; e += 256) {
-      const unsigned long long w = (&s_gn[0][0][0][0])[e];
+    const int b = row0 / HW;                              // the strip lies inside one sample
+    const int slot = (blockIdx.x + blockIdx.y) & (GN_SLOTS - 1);
+    for (int e = threadIdx.x; e < p.gn_n * 32 * GN_WORDS; e += 256) {
+      const unsigned long long w = (&s_gn[0][0][0])[e];
       if (w == 0ull) continue;
-      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, bl = (e / (GN_WORDS * 32)) % 2, t = e / (GN_WORDS * 32 * 2);
-      if (t >= p.gn_n || b0 + bl >= p.B) continue;
-      unsigned long long* dst = (unsigned long long*)p.gn_acc[t] + ((size_t)((b0 + bl) * 32 + g) * GN_SLOTS + slot) * GN_WORDS + word;
-      atomicAdd(dst, w);
+      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, t = e / (GN_WORDS * 32);
+      atomicAdd((unsigned long long*)p.gn_acc[t] + ((size_t)(b * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
     }
   }
 }
@@ -780,9 +804,17 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     SDMI_HIP_OK(hipGetLastError());
     return 0;
   }
-  const int64_t total = (int64_t)p.M * (p.N / 4);
+  // rows per block: 128 (4 steps of 32 rows); with GroupNorm statistics the largest of {256, 128, 64, 32} that divides the
+  // sample's row count, so a strip never straddles two samples
+  int rpb = 128;
+  if (p.gn_n > 0) {
+    const int hw = p.Hout * p.Wout;
+    rpb = hw % 256 == 0 ? 256 : (hw % 128 == 0 ? 128 : (hw % 64 == 0 ? 64 : 32));
+    SDMI_CHECK(hw % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
+  }
   ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, p, nsplit);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(p.N / 4, 8), (unsigned)cdiv(p.M, rpb)), dim3(256), 0, stream, p, nsplit,
+                     rpb);
   SDMI_HIP_OK(hipGetLastError());
   ps2.end();
   if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);
@@ -1009,7 +1041,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   if (p.out_lo) SDMI_CHECK(p.mode == EPI_PLAIN && p.ldo % 4 == 0, "out_lo needs plain mode");
   if (p.gn_n) {
     SDMI_CHECK(p.mode == EPI_PLAIN && p.gn_n <= 2 && (p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need plain mode and Hout*Wout % 32 == 0");
-    SDMI_CHECK(p.N % 4 == 0 && (int64_t)p.Hout * p.Wout >= 1024 / p.N + 2, "GroupNorm statistics: N % 4 == 0, and a reduce block within two samples");
+    SDMI_CHECK(p.N % 4 == 0, "GroupNorm statistics: N % 4 == 0");
     for (int t = 0; t < p.gn_n; ++t)
       SDMI_CHECK(p.gn_acc[t] && p.gn_cpg[t] >= 2 && (p.gn_cbase[t] + p.N + p.gn_cpg[t] - 1) / p.gn_cpg[t] <= 32, "bad GroupNorm statistics target");
   }

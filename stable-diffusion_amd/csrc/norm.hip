@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
       for (int l = 1; l < PL; ++l) { a += lsum[(l - 1) * C + c]; q += lsq[(l - 1) * C + c]; }
       s += a; ss += q;
     }
-    unsigned long long* dst = (unsigned long long*)p.acc + ((size_t)(b * 32 + tid) * GN_SLOTS + (chunk & (GN_SLOTS - 1))) * GN_WORDS;
+    unsigned long long* dst = (unsigned long long*)p.acc + ((size_t)(b * 32 + tid) * GN_SLOTS + (chunk & (GN_SLOTS - 1))) * GN_STRIDE;
     gn_acc_add(dst, s);
     gn_acc_add(dst + 2, ss);
   }
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(256) gn_stats_kernel(GroupNormParams p, int nc
 // fold the GN_SLOTS accumulators of (b, g): called by 8 consecutive lanes (sub = lane & 7), result valid on sub == 0
 __device__ __forceinline__ void gn_fold(const long long* acc, int b, int g, int sub, double n, float eps, float* mean,
                                         float* rstd) {
-  const long long* src = acc + ((size_t)(b * 32 + g) * GN_SLOTS + sub) * GN_WORDS;
+  const long long* src = acc + ((size_t)(b * 32 + g) * GN_SLOTS + sub) * GN_STRIDE;
   long long s = src[0], sl = src[1], ss = src[2], ssl = src[3];
 #pragma unroll
   for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {

@@ -67,7 +67,7 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
         d.heads, d.dh, d.ntok, d.ntok_pad, d.segC = heads['heads'], heads['dh'], heads['ntok'], heads['ntok_pad'], heads['segC']
     d.splitk, d.tile, d.dma = splitk, tile, dma
     d.asym_pad = asym_pad
-    if gn:      # [(acc int64 tensor [B,32,8,4] (zeroed), cpg, cbase)]
+    if gn:      # [(acc int64 tensor [B,32,8,16] (zeroed), cpg, cbase)]
         d.gn_n = len(gn)
         for i, (acc, cpg, cbase) in enumerate(gn):
             d.gn_acc[i] = acc.data_ptr(); d.gn_cpg[i] = cpg; d.gn_cbase[i] = cbase
@@ -80,7 +80,7 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
 
 
 def gn_acc_sums(acc):
-    """accumulator words [B, 32, 8 slots, 4] int64 -> (sum, sumsq) [B, 32] float64"""
+    """accumulator words [B, 32, 8 slots, 16 (4 used: one 128-byte line per slot)] int64 -> (sum, sumsq) [B, 32] float64"""
     a = acc.cpu().to(torch.float64)
     s = (a[..., 0] + a[..., 1] / 2.0 ** 40).sum(-1)
     ss = (a[..., 2] + a[..., 3] / 2.0 ** 40).sum(-1)

@@ -129,8 +129,8 @@ def test_igemm_groupnorm_statistics(tile, splitk, B, H, W, C, N):
     ref = _nhwc(_conv_ref(a, None, w, B, H, W, 3, 1, 0)) + bias[None] + resid        # [M, N]
     cpg0 = N // 20 if N % 20 == 0 else N // 8
     cbase1, cpg1 = 3 * cpg0 + 4, cpg0 + 4
-    acc0 = torch.zeros((B, 32, 8, 4), dtype=torch.int64, device=DEV)
-    acc1 = torch.zeros((B, 32, 8, 4), dtype=torch.int64, device=DEV)
+    acc0 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+    acc1 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
     out = torch.full((B * H * W, N), float('nan'), device=DEV)
     K.igemm(a.to(DEV), K.pack_conv_weight(w.float().to(DEV)), N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV),
             residual=resid.to(DEV), out_f32=out, splitk=splitk, tile=tile, gn=[(acc0, cpg0, 0), (acc1, cpg1, cbase1)])
