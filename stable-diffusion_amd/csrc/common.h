@@ -96,10 +96,11 @@ struct IGemmParams {
   int gn_cpg[2] = {0, 0}, gn_cbase[2] = {0, 0};
   unsigned long long gn_magic[2] = {0, 0};             // ceil(2^40 / gn_cpg), filled by the launcher
   // filled by the launcher: ceil(2^40 / (Hout*Wout)) and ceil(2^40 / Wout) for the kernel's division-free row split
-  unsigned long long magic_hw = 0, magic_w = 0;
+  unsigned long long magic_hw = 0, magic_w = 0, magic_w2 = 0;   // (magic_w2: Wout + 2, halo-staged conv)
+  int log2w = 0;
 };
 
-constexpr int SDMI_NUM_TILES = 14;   // tile ids 0 .. 13, see kTiles in igemm.hip and include/sdmi.h
+constexpr int SDMI_NUM_TILES = 18;   // tile ids 0 .. 17 (14..17: halo-staged 3x3 conv), see kTiles in igemm.hip and include/sdmi.h
 struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes the tuning table's choice)
   int tile = -1;          // -1 auto (tuning table, then heuristic); else a tile id
   int dma = -1;           // -1 default, 0 register-staged loads, 1 global_load_lds

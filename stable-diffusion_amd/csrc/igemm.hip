@@ -55,15 +55,24 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erf_v);
 }
 
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {   // counted wait: the immediate must be a literal
-  static_assert(N >= 0 && N <= 30 && N % 2 == 0, "add the literal");
-#define SDMI_VMCNT_CASE(n) else if constexpr (N == n) asm volatile("s_waitcnt vmcnt(" #n ")" ::: "memory")
-  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  SDMI_VMCNT_CASE(2); SDMI_VMCNT_CASE(4); SDMI_VMCNT_CASE(6); SDMI_VMCNT_CASE(8); SDMI_VMCNT_CASE(10);
-  SDMI_VMCNT_CASE(12); SDMI_VMCNT_CASE(14); SDMI_VMCNT_CASE(16); SDMI_VMCNT_CASE(18); SDMI_VMCNT_CASE(20);
-  SDMI_VMCNT_CASE(22); SDMI_VMCNT_CASE(24); SDMI_VMCNT_CASE(26); SDMI_VMCNT_CASE(28); SDMI_VMCNT_CASE(30);
+// counted wait: the immediate must be a literal; `n` is a compile-time constant at every call site (a template argument,
+// or a value that is constant after loop unrolling), so the switch folds to the one s_waitcnt
+__device__ __forceinline__ void wait_vmcnt_n(int n) {
+  switch (n) {
+#define SDMI_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break
+    SDMI_VMCNT_CASE(0); SDMI_VMCNT_CASE(1); SDMI_VMCNT_CASE(2); SDMI_VMCNT_CASE(3); SDMI_VMCNT_CASE(4); SDMI_VMCNT_CASE(5);
+    SDMI_VMCNT_CASE(6); SDMI_VMCNT_CASE(7); SDMI_VMCNT_CASE(8); SDMI_VMCNT_CASE(9); SDMI_VMCNT_CASE(10); SDMI_VMCNT_CASE(11);
+    SDMI_VMCNT_CASE(12); SDMI_VMCNT_CASE(13); SDMI_VMCNT_CASE(14); SDMI_VMCNT_CASE(15); SDMI_VMCNT_CASE(16);
+    SDMI_VMCNT_CASE(18); SDMI_VMCNT_CASE(20); SDMI_VMCNT_CASE(22); SDMI_VMCNT_CASE(24); SDMI_VMCNT_CASE(26);
+    SDMI_VMCNT_CASE(28); SDMI_VMCNT_CASE(30);
 #undef SDMI_VMCNT_CASE
+    default: __builtin_trap();
+  }
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N <= 30 && (N <= 16 || N % 2 == 0), "add the literal");
+  wait_vmcnt_n(N);
 }
 
 // Kernel kinds: the gather of the implicit A matrix differs, so each is its own instantiation (no runtime branches and no
@@ -75,6 +84,284 @@ enum : int { KIND_1X1 = 0, KIND_3X3 = 1, KIND_3X3_UP = 2 };
 __device__ __forceinline__ int fast_div(int m, unsigned long long magic) {
   return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
 }
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// The epilogue shared by the GEMM kernels (generic implicit GEMM and the halo-staged 3x3 convolution): accumulators of the
+// wave's TM x TN MFMA tiles -> bias / time-embedding row vector / residual / fp32 + fp16 (+ split-fp16 low half) stores,
+// GEGLU, per-head q / k / v^T scatter, split-K slabs, GroupNorm statistics.  `smem` = the block's LDS (free at this point:
+// every LDS-DMA of the block has landed and is no longer read), LDS_BYTES its size.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int LDS_BYTES>
+__device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[BM / WARPS_M / 32][BN / WARPS_N / 32],
+                                               const int m0, const int n0, const int split, const int tile_m,
+                                               const int tile_n, unsigned char* smem) {
+  constexpr int NT = WARPS_M * WARPS_N * 64;
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+  const int l31 = lane & 31, lg = lane >> 5;
+  const int HWout = p.Hout * p.Wout;
+  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+  // Full interior tiles take a branch-free path: all residual loads of a 32-row slab are issued back to back
+  // (independent), column terms are hoisted, and no per-element bounds checks split the stores into dependent
+  // load -> wait -> store chains (those chains were ~70 % of the short-K kernels' time, profiles/ablate2_r01.txt).
+  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if (p.mode == EPI_PLAIN) {
+    const bool atomic = p.splitk > 1;      // split-K: raw partial sums go to this split's slab
+    float* slab = atomic ? (p.splitk_ws + (size_t)split * p.M * p.N) : nullptr;
+    const int b_first = m0 / HWout;
+    const bool one_batch = ((m0 + BM - 1) / HWout == b_first);
+    if (full && one_batch) {
+      if (atomic) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            float* row = slab + (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.N + nw + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) row[j * 32] = acc[i][j][r];
+          }
+      } else {
+        float colv[TN];
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          const int n = nw + j * 32 + l31;
+          colv[j] = p.bias ? p.bias[n] : 0.f;
+          if (p.rowvec) colv[j] += p.rowvec[(size_t)b_first * p.ld_rowvec + n];
+        }
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          float resv[16][TN];
+          if (p.residual) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const float* row = p.residual + (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.ldr + nw + l31;
+#pragma unroll
+              for (int j = 0; j < TN; ++j) resv[r][j] = row[j * 32];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+              for (int j = 0; j < TN; ++j) resv[r][j] = 0.f;
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const size_t ro = (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.ldo + nw + l31;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+              const float v = acc[i][j][r] + colv[j] + resv[r][j];
+              acc[i][j][r] = v;                       // final value, kept for the GroupNorm statistics below
+              if (p.out_f32) p.out_f32[ro + j * 32] = v;
+              if (p.out_f16) p.out_f16[ro + j * 32] = (f16)v;
+              if (p.out_lo) p.out_lo[ro + j * 32] = (f16)(v - (float)(f16)v);
+            }
+          }
+        }
+      }
+    } else {
+      float bias_v[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + l31;
+        bias_v[j] = (!atomic && p.bias && n < p.N) ? p.bias[n] : 0.f;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (m >= p.M) continue;
+          const float* rv = (!atomic && p.rowvec) ? (p.rowvec + (size_t)(m / HWout) * p.ld_rowvec) : nullptr;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 32 + l31;
+            if (n >= p.N) continue;
+            float v = acc[i][j][r];
+            if (atomic) {
+              slab[(size_t)m * p.N + n] = v;
+            } else {
+              v += bias_v[j];
+              if (rv) v += rv[n];
+              if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
+              acc[i][j][r] = v;
+              if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
+              if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
+              if (p.out_lo) p.out_lo[(size_t)m * p.ldo + n] = (f16)(v - (float)(f16)v);
+            }
+          }
+        }
+      }
+    }
+    // ---- GroupNorm statistics of the finished output, for the GroupNorm(s) that will read it (up to two: the next
+    // layer's, and the skip-concat's of an output block): {sum, sum of squares} per (sample, group) of this tile, added as
+    // fixed-point int64 to the consumer's accumulators -- the same words norm.hip's statistics kernel fills, so that
+    // kernel (one launch per GroupNorm) is not needed.  Integer adds are associative: bit-reproducible.  The waves of the
+    // block first combine in LDS (the tile buffers are free now), so the block issues ONE global atomic set per
+    // (sample, group) it touched: the global adds, not the arithmetic, are what statistics cost.
+    // Needs Hout*Wout % 32 == 0 (a 32-row MFMA tile lies inside one sample); the executor checks it.
+    if (p.gn_n > 0 && !atomic) {
+      constexpr int GNB = BM / 32;                        // samples a tile can touch (Hout*Wout >= 32)
+      unsigned long long* lacc = (unsigned long long*)smem;                  // [target][sample in tile][group][GN_WORDS]
+      static_assert(2 * GNB * 32 * GN_WORDS * 8 <= LDS_BYTES, "LDS too small for the statistics accumulators");
+      __syncthreads();                                    // every wave's LDS-DMA has landed (wait_vmcnt<0> above) and is unread
+      for (int e = tid; e < 2 * GNB * 32 * GN_WORDS; e += NT) lacc[e] = 0ull;
+      __syncthreads();
+      const int b_tile = m0 / HWout;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + l31;
+        const bool nvalid = n < p.N;
+        auto flush = [&](int b, float s1, float s2) {
+          if (!nvalid) { s1 = 0.f; s2 = 0.f; }
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);         // the two half-waves hold disjoint rows of a column
+          for (int t = 0; t < p.gn_n; ++t) {
+            const int gid = nvalid ? fast_div(p.gn_cbase[t] + n, p.gn_magic[t]) : -1;
+            float a1 = s1, a2 = s2;
+#pragma unroll
+            for (int off = 1; off < 32; off <<= 1) {                   // segmented sum over runs of equal group id
+              const float t1 = __shfl_down(a1, off, 32), t2 = __shfl_down(a2, off, 32);
+              const int tg = __shfl_down(gid, off, 32);
+              if (l31 + off < 32 && tg == gid) { a1 += t1; a2 += t2; }
+            }
+            const int gprev = __shfl_up(gid, 1, 32);
+            if (lg == 0 && gid >= 0 && (l31 == 0 || gprev != gid)) {
+              unsigned long long* dst = lacc + ((size_t)(t * GNB + (b - b_tile)) * 32 + gid) * GN_WORDS;
+              gn_acc_add(dst, a1);
+              gn_acc_add(dst + 2, a2);
+            }
+          }
+        };
+        float s1 = 0.f, s2 = 0.f;
+        int bcur = -1;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mt = mw + i * 32;                  // wave-uniform
+          if (mt < p.M) {
+            const int bi = mt / HWout;
+            if (bcur >= 0 && bi != bcur) { flush(bcur, s1, s2); s1 = 0.f; s2 = 0.f; }
+            bcur = bi;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              if (m < p.M) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
+            }
+          }
+        }
+        if (bcur >= 0) flush(bcur, s1, s2);
+      }
+      __syncthreads();
+      const int slot = (tile_m + tile_n) & (GN_SLOTS - 1);
+      for (int e = tid; e < p.gn_n * GNB * 32 * GN_WORDS; e += NT) {
+        const unsigned long long w = lacc[e];
+        if (w == 0ull) continue;
+        const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, bl = (e / (GN_WORDS * 32)) % GNB, t = e / (GN_WORDS * 32 * GNB);
+        if (b_tile + bl >= p.B) continue;
+        atomicAdd((unsigned long long*)p.gn_acc[t] + ((size_t)((b_tile + bl) * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
+      }
+    }
+  } else if (p.mode == EPI_GEGLU) {
+    if constexpr (TN % 2 == 0) {
+#pragma unroll
+      for (int j2 = 0; j2 < TN / 2; ++j2) {
+        const int nv = nw + (2 * j2) * 32 + l31;      // value column (packed order), gate = nv + 32
+        if (nv >= p.N) continue;
+        const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[nv + 32] : 0.f;
+        const int oc = (nw >> 1) + j2 * 32 + l31;
+        if (full) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              const float val = acc[i][2 * j2][r] + bv;
+              const float gate = acc[i][2 * j2 + 1][r] + bg;
+              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
+            }
+        } else {
+#pragma unroll
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+              if (m >= p.M) continue;
+              const float val = acc[i][2 * j2][r] + bv;
+              const float gate = acc[i][2 * j2 + 1][r] + bg;
+              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
+            }
+        }
+      }
+    }
+  } else {  // EPI_HEADS
+    if (p.splitk > 1) {   // split-K: raw partial tile to this split's slab; splitk_reduce_heads_kernel scatters the sum
+      float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
+          if (m >= p.M) continue;
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            const int n = nw + j * 32 + l31;
+            if (n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
+          }
+        }
+      return;
+    }
+    // lane = output column (seg, head, dd); registers 4q..4q+3 = 4 consecutive rows (tokens)
+    const bool vec4 = (p.ntok % 4 == 0) && (p.ntok_pad % 4 == 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = nw + j * 32 + l31;
+      if (n >= p.N) continue;
+      const int seg = n / p.segC;
+      const int c = n - seg * p.segC;
+      const int head = c / p.dh;
+      const int dd = c - head * p.dh;
+      f16* dst = p.seg_dst[seg];
+      const int kind = p.seg_kind[seg];
+      if (p.bias) {                        // q/k/v projections with a bias (CLIP text model); the UNet's have none
+        const float bv = p.bias[n];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int mq = mw + i * 32 + 8 * r4 + 4 * lg;       // first of 4 consecutive rows (multiple of 4)
+          if (mq >= p.M) continue;
+          const int b = mq / p.ntok;
+          const int tok = mq - b * p.ntok;
+          const size_t bh = (size_t)b * p.heads + head;
+          if (kind == 1 && vec4 && mq + 3 < p.M) {
+            *(f16x4*)(dst + (bh * p.dh + dd) * p.ntok_pad + tok) =
+                f16x4{(f16)acc[i][j][r4 * 4 + 0], (f16)acc[i][j][r4 * 4 + 1], (f16)acc[i][j][r4 * 4 + 2],
+                      (f16)acc[i][j][r4 * 4 + 3]};
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int m = mq + e;
+              if (m >= p.M) continue;
+              const int b2 = m / p.ntok;
+              const int t2 = m - b2 * p.ntok;
+              const size_t bh2 = (size_t)b2 * p.heads + head;
+              const size_t off = kind == 0 ? ((bh2 * p.ntok + t2) * p.dh + dd) : ((bh2 * p.dh + dd) * p.ntok_pad + t2);
+              dst[off] = (f16)acc[i][j][r4 * 4 + e];
+            }
+          }
+        }
+    }
+  }
+}
+
+#endif  // __HIP_DEVICE_COMPILE__
 
 // NS = LDS pipeline depth.  DMA path: NS-1 k-tiles are in flight across the (raw) barrier, retired by a counted
 // s_waitcnt vmcnt(N); the global->LDS latency (~1 us under load) is several k-tiles of MFMA work, so NS = 2 leaves
@@ -375,262 +662,230 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
-  // C/D layout of 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-  const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
-  // Full interior tiles take a branch-free path: all residual loads of a 32-row slab are issued back to back
-  // (independent), column terms are hoisted, and no per-element bounds checks split the stores into dependent
-  // load -> wait -> store chains (those chains were ~70 % of the short-K kernels' time, profiles/ablate2_r01.txt).
-  const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-  if (p.mode == EPI_PLAIN) {
-    const bool atomic = p.splitk > 1;      // split-K: raw partial sums go to this split's slab
-    float* slab = atomic ? (p.splitk_ws + (size_t)split * p.M * p.N) : nullptr;
-    const int b_first = m0 / HWout;
-    const bool one_batch = ((m0 + BM - 1) / HWout == b_first);
-    if (full && one_batch) {
-      if (atomic) {
+  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
+// ---- halo-staged 3x3 convolution (stride 1, pad 1) --------------------------------------------------------------------
+// ResBlock in_layers / out_layers convs (openaimodel.py:204,230) at the 64x64 .. 16x16 levels.  The generic kernel above
+// streams the A operand once per TAP: the nine shifted copies of the same pixels are nine separate k-tiles, so a 3x3 conv
+// moves 9x its activation bytes through the CU's vector-memory path -- and that path (64 B/clk/CU), not MFMA issue, is
+// what bounds these 15 GFLOP launches.  Here a block owns TH = BM / W whole image rows; for every 64-channel chunk it
+// stages the (TH + 2) x (W + 2) input HALO once (LDS-DMA; out-of-image pixels are out-of-range buffer offsets and read as
+// zeros) and all nine taps read their A fragments from it at a row offset -- only the weights stream per tap.
+// Bytes through the vector-memory path per chunk, 256 x 64 tile: 51 KB halo + 72 KB weights vs 9 x 40 KB = 360 KB.
+//   LDS: [halo buffer 0 | halo buffer 1 | NS weight stages]; halo rows are pixels (128 B = 64 channels), XOR-swizzled by
+//   the absolute LDS row exactly like the generic tiles, so fragment reads at any row offset stay conflict free.
+//   The nine taps are unrolled: every DMA issue and every counted vmcnt wait is static.
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
+__global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const IGemmParams p, const int tiles_m,
+                                                                           const int tiles_n, const int chunks_per_split) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NT = WARPS_M * WARPS_N * 64;
+  constexpr int RPP = NT / 8;
+  constexpr int PB = BN / RPP;                         // weight DMA pieces per thread per tap
+  constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
+  constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int HPMAX = (BM / 64 + 2) * 66;            // halo pixels at W = 64 (the largest for W in {16, 32, 64})
+  constexpr int AHP = (HPMAX + RPP - 1) / RPP;         // halo DMA pieces per thread per chunk
+  constexpr int HALO_BYTES = AHP * RPP * 128;
+  constexpr int BSTAGE = BN * 128;
+  constexpr int LDS_BYTES = 2 * HALO_BYTES + NS * BSTAGE;
+  constexpr int PA = (AHP + 7) / 8;                    // halo pieces of the NEXT chunk issued per tap (taps 0..7)
+  constexpr int KS = BK / 16;
+  constexpr int G = (TM * TN >= 4) ? 1 : 2;            // k-steps per pipeline unit (>= 4 MFMAs of cover)
+  constexpr int U = KS / G;
+  constexpr int MPU = G * TM * TN;
+  static_assert(PB >= 1 && TM >= 1 && TN >= 1 && RPP % 16 == 0 && NS >= 2 && NS <= 3, "tile/wave shape");
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
+
+  const int nblk = gridDim.x;
+  const int bid = blockIdx.x;
+  const int q8 = nblk >> 3, r8 = nblk & 7, xcd = bid & 7;
+  const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (bid >> 3);
+  const int tiles_mn = tiles_m * tiles_n;
+  const int split = wgid / tiles_mn;
+  const int tmn = wgid - split * tiles_mn;
+  const int tile_n = tmn / tiles_m;
+  const int tile_m = tmn - tile_n * tiles_m;
+  const int m0 = tile_m * BM, n0 = tile_n * BN;
+  const int nch = (p.c0 + p.c1 + p.c2) / BK;
+  const int c_begin = split * chunks_per_split;
+  const int c_end = min(nch, c_begin + chunks_per_split);
+  if (c_begin >= c_end) return;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int cpos = tid & 7, lrow = tid >> 3;
+  const int gch = cpos ^ ((lrow >> 1) & 7);
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+  const int l31 = lane & 31, lg = lane >> 5;
+  const int rsw = (l31 >> 1) & 7;
+
+  const int W = p.Wout, H = p.Hout, HW = H * W, W2 = W + 2, ld = p.lda0;
+  const int bimg = m0 / HW;
+  const int y0 = (m0 - bimg * HW) >> p.log2w;
+  const int TH = BM >> p.log2w;
+  const int HP = (TH + 2) * W2;
+  constexpr int OOB = (int)0x80000000;
+
+  // per-lane source byte offset of every halo piece (constant over the chunks: the chunk moves the scalar offset)
+  int hvoff[AHP];
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+  for (int q = 0; q < AHP; ++q) {
+    const int hp = q * RPP + lrow;
+    const int hy = fast_div(hp, p.magic_w2), hx = hp - hy * W2;
+    const int y = y0 + hy - 1, x = hx - 1;
+    const bool valid = hp < HP && y >= 0 && y < H && x >= 0 && x < W;
+    hvoff[q] = valid ? (((bimg * H + y) * W + x) * ld + gch * 8) * 2 : OOB;
+  }
+  int b_off[PB];
 #pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            float* row = slab + (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.N + nw + l31;
+  for (int i = 0; i < PB; ++i) {
+    const int n = min(n0 + i * RPP + lrow, p.N - 1);
+    b_off[i] = (n * p.K + gch * 8) * 2;
+  }
+  // halo row of tap (0, 0) for the rows of this lane's MFMA tiles
+  int hr0[TM];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) row[j * 32] = acc[i][j][r];
+  for (int i = 0; i < TM; ++i) {
+    const int ml = wm * WTM + i * 32 + l31;
+    hr0[i] = (ml >> p.log2w) * W2 + (ml & (W - 1));
+  }
+  const int b_lds = 2 * HALO_BYTES + (wn * WTN + l31) * 128;
+
+  const char* const srcA0 = (const char*)p.a0; const char* const srcA1 = (const char*)p.a1;
+  const char* const srcA2 = (const char*)p.a2;
+  const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, OOB, 0x00020000);
+  const int pc0 = p.c0, pc01 = p.c0 + p.c1;
+  struct ChunkSrc { __amdgpu_buffer_rsrc_t rsrc; int soff; };
+  auto chunk_src = [&](int c) {
+    const int cin0 = c * BK;
+    const char* src; int coff;
+    if (cin0 < pc0) { src = srcA0; coff = cin0; }
+    else if (cin0 < pc01) { src = srcA1; coff = cin0 - pc0; }
+    else { src = srcA2; coff = cin0 - pc01; }
+    ChunkSrc r; r.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, OOB, 0x00020000); r.soff = coff * 2;
+    return r;
+  };
+  auto issue_halo = [&](const ChunkSrc& cs, int hbuf, int q) {
+    auto dst = (__attribute__((address_space(3))) void*)(smem + hbuf * HALO_BYTES + (q * RPP + wave_u * 8) * 128);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(cs.rsrc, dst, 16, hvoff[q], cs.soff, 0, 0);
+  };
+  auto issue_b = [&](int kt, int stage, int q) {
+    auto dst = (__attribute__((address_space(3))) void*)(smem + 2 * HALO_BYTES + stage * BSTAGE + (q * RPP + wave_u * 8) * 128);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q], kt * (BK * 2), 0, 0);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  // LDS byte address (k-step 0) of the A fragment rows of MFMA tile i for tap (ky, kx) in halo buffer hbuf;
+  // k-step ks is that address ^ (ks << 5) (the 16-byte chunk index is (2 ks + lg) ^ swizzle(row))
+  auto a_base = [&](int i, int ky, int kx, int hbuf) -> int {
+    const int rowt = hr0[i] + ky * W2 + kx;
+    return hbuf * HALO_BYTES + ((rowt << 7) | ((lg ^ ((rowt >> 1) & 7)) << 4));
+  };
+  auto read_frags = [&](const int (&ab)[TM], int bstage, int ks, f16x8 (&a)[TM], f16x8 (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i) a[i] = *(const f16x8*)(smem + (ab[i] ^ (ks << 5)));
+    const unsigned char* st = smem + bstage * BSTAGE + b_lds + (((ks * 2 + lg) ^ rsw) << 4);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b[j] = *(const f16x8*)(st + j * 32 * 128);
+  };
+  auto mfma_step = [&](const f16x8 (&a)[TM], const f16x8 (&b)[TN]) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
+  };
+
+  // ---- prologue: first halo, first NS - 1 weight tiles ------------------------------------------------------------
+  const int kt_first = c_begin * 9, kt_last = c_end * 9 - 1;
+  {
+    const ChunkSrc cs = chunk_src(c_begin);
+#pragma unroll
+    for (int q = 0; q < AHP; ++q) issue_halo(cs, 0, q);
+#pragma unroll
+    for (int s2 = 0; s2 < NS - 1; ++s2)
+#pragma unroll
+      for (int q = 0; q < PB; ++q) issue_b(min(kt_first + s2, kt_last), s2, q);
+  }
+  wait_vmcnt<(NS - 2) * PB>();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  f16x8 fa[2][G][TM], fb[2][G][TN];
+  int ab[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) ab[i] = a_base(i, 0, 0, 0);
+#pragma unroll
+  for (int g = 0; g < G; ++g) read_frags(ab, 0, g, fa[0][g], fb[0][g]);
+
+  int cur = 0, nxt = NS - 1, hb = 0;
+  for (int c = c_begin; c < c_end; ++c) {
+    // the next chunk's halo streams in during taps 0..7 (the last chunk of the split reloads itself: same issue counts,
+    // so every vmcnt literal below stays valid)
+    const ChunkSrc csn = chunk_src(min(c + 1, c_end - 1));
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int kt = c * 9 + tap;
+      const int tap1 = tap == 8 ? 0 : tap + 1;
+      const int hb1 = tap == 8 ? (hb ^ 1) : hb;
+      const int cur1 = (cur + 1 == NS) ? 0 : cur + 1;
+      int ab1[TM];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) ab1[i] = a_base(i, tap1 / 3, tap1 % 3, hb1);
+      const int a_lo = tap < 8 ? (tap * PA < AHP ? tap * PA : AHP) : AHP;
+      const int a_hi = tap < 8 ? ((tap + 1) * PA < AHP ? (tap + 1) * PA : AHP) : AHP;
+      const int na = a_hi - a_lo;                       // compile-time after unrolling
+      const int npieces = na + PB;
+      const int ppu = (npieces + U - 2) / (U - 1);
+      const int bt = min(kt + NS - 1, kt_last);
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        if (u + 1 < U) {
+#pragma unroll
+          for (int g = 0; g < G; ++g) read_frags(ab, cur, (u + 1) * G + g, fa[(u + 1) & 1][g], fb[(u + 1) & 1][g]);
+#pragma unroll
+          for (int e = u * ppu; e < (u + 1) * ppu && e < npieces; ++e) {
+            if (e < na) issue_halo(csn, hb ^ 1, a_lo + e);        // halo pieces first: older than this tap's weights
+            else issue_b(bt, nxt, e - na);
           }
-      } else {
-        float colv[TN];
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          const int n = nw + j * 32 + l31;
-          colv[j] = p.bias ? p.bias[n] : 0.f;
-          if (p.rowvec) colv[j] += p.rowvec[(size_t)b_first * p.ld_rowvec + n];
-        }
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          float resv[16][TN];
-          if (p.residual) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const float* row = p.residual + (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.ldr + nw + l31;
-#pragma unroll
-              for (int j = 0; j < TN; ++j) resv[r][j] = row[j * 32];
-            }
-          } else {
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-#pragma unroll
-              for (int j = 0; j < TN; ++j) resv[r][j] = 0.f;
-          }
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const size_t ro = (size_t)(mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg) * p.ldo + nw + l31;
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-              const float v = acc[i][j][r] + colv[j] + resv[r][j];
-              acc[i][j][r] = v;                       // final value, kept for the GroupNorm statistics below
-              if (p.out_f32) p.out_f32[ro + j * 32] = v;
-              if (p.out_f16) p.out_f16[ro + j * 32] = (f16)v;
-              if (p.out_lo) p.out_lo[ro + j * 32] = (f16)(v - (float)(f16)v);
-            }
-          }
-        }
-      }
-    } else {
-      float bias_v[TN];
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = nw + j * 32 + l31;
-        bias_v[j] = (!atomic && p.bias && n < p.N) ? p.bias[n] : 0.f;
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-          if (m >= p.M) continue;
-          const float* rv = (!atomic && p.rowvec) ? (p.rowvec + (size_t)(m / HWout) * p.ld_rowvec) : nullptr;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int n = nw + j * 32 + l31;
-            if (n >= p.N) continue;
-            float v = acc[i][j][r];
-            if (atomic) {
-              slab[(size_t)m * p.N + n] = v;
-            } else {
-              v += bias_v[j];
-              if (rv) v += rv[n];
-              if (p.residual) v += p.residual[(size_t)m * p.ldr + n];
-              acc[i][j][r] = v;
-              if (p.out_f32) p.out_f32[(size_t)m * p.ldo + n] = v;
-              if (p.out_f16) p.out_f16[(size_t)m * p.ldo + n] = (f16)v;
-              if (p.out_lo) p.out_lo[(size_t)m * p.ldo + n] = (f16)(v - (float)(f16)v);
-            }
-          }
-        }
-      }
-    }
-    // ---- GroupNorm statistics of the finished output, for the GroupNorm(s) that will read it (up to two: the next
-    // layer's, and the skip-concat's of an output block): {sum, sum of squares} per (sample, group) of this tile, added as
-    // fixed-point int64 to the consumer's accumulators -- the same words norm.hip's statistics kernel fills, so that
-    // kernel (one launch per GroupNorm) is not needed.  Integer adds are associative: bit-reproducible.  The waves of the
-    // block first combine in LDS (the tile buffers are free now), so the block issues ONE global atomic set per
-    // (sample, group) it touched: the global adds, not the arithmetic, are what statistics cost.
-    // Needs Hout*Wout % 32 == 0 (a 32-row MFMA tile lies inside one sample); the executor checks it.
-    if (p.gn_n > 0 && !atomic) {
-      constexpr int GNB = BM / 32;                        // samples a tile can touch (Hout*Wout >= 32)
-      unsigned long long* lacc = (unsigned long long*)smem;                  // [target][sample in tile][group][GN_WORDS]
-      static_assert(2 * GNB * 32 * GN_WORDS * 8 <= NS * STAGE_BYTES, "LDS too small for the statistics accumulators");
-      __syncthreads();                                    // every wave's LDS-DMA has landed (wait_vmcnt<0> above) and is unread
-      for (int e = tid; e < 2 * GNB * 32 * GN_WORDS; e += NT) lacc[e] = 0ull;
-      __syncthreads();
-      const int b_tile = m0 / HWout;
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int n = nw + j * 32 + l31;
-        const bool nvalid = n < p.N;
-        auto flush = [&](int b, float s1, float s2) {
-          if (!nvalid) { s1 = 0.f; s2 = 0.f; }
-          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);         // the two half-waves hold disjoint rows of a column
-          for (int t = 0; t < p.gn_n; ++t) {
-            const int gid = nvalid ? fast_div(p.gn_cbase[t] + n, p.gn_magic[t]) : -1;
-            float a1 = s1, a2 = s2;
-#pragma unroll
-            for (int off = 1; off < 32; off <<= 1) {                   // segmented sum over runs of equal group id
-              const float t1 = __shfl_down(a1, off, 32), t2 = __shfl_down(a2, off, 32);
-              const int tg = __shfl_down(gid, off, 32);
-              if (l31 + off < 32 && tg == gid) { a1 += t1; a2 += t2; }
-            }
-            const int gprev = __shfl_up(gid, 1, 32);
-            if (lg == 0 && gid >= 0 && (l31 == 0 || gprev != gid)) {
-              unsigned long long* dst = lacc + ((size_t)(t * GNB + (b - b_tile)) * 32 + gid) * GN_WORDS;
-              gn_acc_add(dst, a1);
-              gn_acc_add(dst + 2, a2);
-            }
-          }
-        };
-        float s1 = 0.f, s2 = 0.f;
-        int bcur = -1;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-          const int mt = mw + i * 32;                  // wave-uniform
-          if (mt < p.M) {
-            const int bi = mt / HWout;
-            if (bcur >= 0 && bi != bcur) { flush(bcur, s1, s2); s1 = 0.f; s2 = 0.f; }
-            bcur = bi;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int m = mt + (r & 3) + 8 * (r >> 2) + 4 * lg;
-              if (m < p.M) { const float v = acc[i][j][r]; s1 += v; s2 += v * v; }
-            }
-          }
-        }
-        if (bcur >= 0) flush(bcur, s1, s2);
-      }
-      __syncthreads();
-      const int slot = (tile_m + tile_n) & (GN_SLOTS - 1);
-      for (int e = tid; e < p.gn_n * GNB * 32 * GN_WORDS; e += NT) {
-        const unsigned long long w = lacc[e];
-        if (w == 0ull) continue;
-        const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, bl = (e / (GN_WORDS * 32)) % GNB, t = e / (GN_WORDS * 32 * GNB);
-        if (b_tile + bl >= p.B) continue;
-        atomicAdd((unsigned long long*)p.gn_acc[t] + ((size_t)((b_tile + bl) * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
-      }
-    }
-  } else if (p.mode == EPI_GEGLU) {
-    if constexpr (TN % 2 == 0) {
-#pragma unroll
-      for (int j2 = 0; j2 < TN / 2; ++j2) {
-        const int nv = nw + (2 * j2) * 32 + l31;      // value column (packed order), gate = nv + 32
-        if (nv >= p.N) continue;
-        const float bv = p.bias ? p.bias[nv] : 0.f, bg = p.bias ? p.bias[nv + 32] : 0.f;
-        const int oc = (nw >> 1) + j2 * 32 + l31;
-        if (full) {
-#pragma unroll
-          for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-              const float val = acc[i][2 * j2][r] + bv;
-              const float gate = acc[i][2 * j2 + 1][r] + bg;
-              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
-            }
         } else {
+          // allowed in flight: what the last NS - 2 taps issued (this tap's pieces for NS = 3): weight tile kt + 1 --
+          // and, at tap 8, the whole next halo (issued at taps <= 7) -- has landed for this wave; the barrier makes it
+          // everybody's, and tells everybody this tile's LDS reads are done
+          if (NS == 3) wait_vmcnt_n(na + PB); else wait_vmcnt_n(0);
+          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+          for (int g = 0; g < G; ++g) read_frags(ab1, cur1, g, fa[0][g], fb[0][g]);
+        }
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-              if (m >= p.M) continue;
-              const float val = acc[i][2 * j2][r] + bv;
-              const float gate = acc[i][2 * j2 + 1][r] + bg;
-              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
-            }
+        for (int g = 0; g < G; ++g) mfma_step(fa[u & 1][g], fb[u & 1][g]);
+        __builtin_amdgcn_sched_group_barrier(0x100, G * (TM + TN), 0);
+#pragma unroll
+        for (int e = 0; e < MPU; ++e) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (u + 1 < U && e < ppu && u * ppu + e < npieces) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
         }
       }
-    }
-  } else {  // EPI_HEADS
-    if (p.splitk > 1) {   // split-K: raw partial tile to this split's slab; splitk_reduce_heads_kernel scatters the sum
-      float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
-          if (m >= p.M) continue;
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            const int n = nw + j * 32 + l31;
-            if (n < p.N) slab[(size_t)m * p.N + n] = acc[i][j][r];
-          }
-        }
-      return;
-    }
-    // lane = output column (seg, head, dd); registers 4q..4q+3 = 4 consecutive rows (tokens)
-    const bool vec4 = (p.ntok % 4 == 0) && (p.ntok_pad % 4 == 0);
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int n = nw + j * 32 + l31;
-      if (n >= p.N) continue;
-      const int seg = n / p.segC;
-      const int c = n - seg * p.segC;
-      const int head = c / p.dh;
-      const int dd = c - head * p.dh;
-      f16* dst = p.seg_dst[seg];
-      const int kind = p.seg_kind[seg];
-      if (p.bias) {                        // q/k/v projections with a bias (CLIP text model); the UNet's have none
-        const float bv = p.bias[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4) {
-          const int mq = mw + i * 32 + 8 * r4 + 4 * lg;       // first of 4 consecutive rows (multiple of 4)
-          if (mq >= p.M) continue;
-          const int b = mq / p.ntok;
-          const int tok = mq - b * p.ntok;
-          const size_t bh = (size_t)b * p.heads + head;
-          if (kind == 1 && vec4 && mq + 3 < p.M) {
-            *(f16x4*)(dst + (bh * p.dh + dd) * p.ntok_pad + tok) =
-                f16x4{(f16)acc[i][j][r4 * 4 + 0], (f16)acc[i][j][r4 * 4 + 1], (f16)acc[i][j][r4 * 4 + 2],
-                      (f16)acc[i][j][r4 * 4 + 3]};
-          } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const int m = mq + e;
-              if (m >= p.M) continue;
-              const int b2 = m / p.ntok;
-              const int t2 = m - b2 * p.ntok;
-              const size_t bh2 = (size_t)b2 * p.heads + head;
-              const size_t off = kind == 0 ? ((bh2 * p.ntok + t2) * p.dh + dd) : ((bh2 * p.dh + dd) * p.ntok_pad + t2);
-              dst[off] = (f16)acc[i][j][r4 * 4 + e];
-            }
-          }
-        }
+      for (int i = 0; i < TM; ++i) ab[i] = ab1[i];
+      cur = cur1;
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+      hb = hb1;
     }
   }
+  wait_vmcnt<0>();
+  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, LDS_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -804,20 +1059,61 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     SDMI_HIP_OK(hipGetLastError());
     return 0;
   }
-  // rows per block: 128 (4 steps of 32 rows); with GroupNorm statistics the largest of {256, 128, 64, 32} that divides the
-  // sample's row count, so a strip never straddles two samples
-  int rpb = 128;
-  if (p.gn_n > 0) {
-    const int hw = p.Hout * p.Wout;
-    rpb = hw % 256 == 0 ? 256 : (hw % 128 == 0 ? 128 : (hw % 64 == 0 ? 64 : 32));
-    SDMI_CHECK(hw % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
-  }
+  // rows per block: 32 (one row per thread) up to 256, doubling while the grid keeps >= 1024 blocks (the kernel is a
+  // latency-bound stream of nsplit 16-byte loads per thread: it wants every CU busy); with GroupNorm statistics it must
+  // also divide the sample's row count, so a strip never straddles two samples
+  int rpb = 32;
+  const int hw = p.Hout * p.Wout;
+  if (p.gn_n > 0) SDMI_CHECK(hw % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
+  while (rpb < 256 && (int64_t)cdiv(p.N / 4, 8) * cdiv(p.M, rpb * 2) >= 1024 && (p.gn_n == 0 || hw % (rpb * 2) == 0)) rpb *= 2;
   ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(p.N / 4, 8), (unsigned)cdiv(p.M, rpb)), dim3(256), 0, stream, p, nsplit,
                      rpb);
   SDMI_HIP_OK(hipGetLastError());
   ps2.end();
   if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);
+  return 0;
+}
+
+// halo-staged 3x3 convolution: supported iff stride 1, pad 1, no upsampling, power-of-two width 16..64 and tiles of whole
+// image rows that do not straddle samples
+static bool halo_supported(const IGemmParams& p, int bm) {
+  const int W = p.Wout;
+  return p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.up && p.Hin == p.Hout && p.Win == p.Wout && W >= 16 && W <= 64 &&
+         (W & (W - 1)) == 0 && bm % W == 0 && (p.Hout * p.Wout) % bm == 0;
+}
+
+template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
+int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
+  SDMI_CHECK(halo_supported(p, BM), "halo-staged conv tile requested for an unsupported shape");
+  const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
+  const int nch = (p.c0 + p.c1 + p.c2) / BK;
+  const int chunks_per_split = cdiv(nch, splitk);
+  const int nsplit = cdiv(nch, chunks_per_split);
+  IGemmParams q = p;
+  q.splitk = nsplit;
+  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_w = div_magic(p.Wout);
+  q.magic_w2 = div_magic(p.Wout + 2);
+  q.log2w = 0;
+  while ((1 << q.log2w) < p.Wout) ++q.log2w;
+  for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
+  dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
+  static const int by_shape = env_int("SDMI_PROF_SHAPES", 0);
+  std::string pname = std::string("conv3halo_") + std::to_string(BM) + "x" + std::to_string(BN) + "w" +
+                      std::to_string(WARPS_M * WARPS_N) + "s" + std::to_string(NS);
+  if (by_shape && prof_enabled())
+    pname += "_M" + std::to_string(p.M) + "_N" + std::to_string(p.N) + "_K" + std::to_string(p.K) + "_s" + std::to_string(nsplit);
+  const double src_pix = (double)p.B * p.Hin * p.Win;
+  ProfScope ps(pname.c_str(), 2.0 * p.M * (double)p.N * p.K,
+               src_pix * (p.c0 + p.c1) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_f16 ? 2.0 : 0.0)) +
+                   (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
+               stream);
+  hipLaunchKernelGGL((conv3halo_kernel<BM, BN, WARPS_M, WARPS_N, NS>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
+  SDMI_HIP_OK(hipGetLastError());
+  ps.end();
+  if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);
+  if (q.ln_out) return launch_layernorm(q.out_f32, q.ln_gamma, q.ln_beta, q.ln_out, q.M, q.N, q.ln_eps, stream);
   return 0;
 }
 
@@ -839,7 +1135,14 @@ static const TileCfg kTiles[SDMI_NUM_TILES] = {
     {128, 256, 2, 4, 2},   // 11  8 waves, 2x2, 96 KB
     {64, 256, 1, 4, 3},    // 12  4 waves, 2x2, 120 KB (small M, wide N: one A tile shared by the 4 waves)
     {256, 64, 4, 1, 3},    // 13  4 waves, 2x2, 120 KB (large M, N = 5 x 64)
+    // halo-staged 3x3 convolution (conv3halo_kernel): tiles of whole image rows
+    {256, 64, 4, 2, 3},    // 14  8 waves, 2x1 per wave
+    {256, 128, 4, 2, 2},   // 15  8 waves, 2x2
+    {128, 64, 2, 2, 3},    // 16  4 waves, 2x1
+    {128, 128, 2, 2, 3},   // 17  4 waves, 2x2
 };
+constexpr int SDMI_FIRST_HALO_TILE = 14;
+static inline bool tile_is_halo(int t) { return t >= SDMI_FIRST_HALO_TILE; }
 static inline bool tile_tn_even(int t) { return (kTiles[t].bn / kTiles[t].wn / 32) % 2 == 0; }
 
 static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
@@ -858,6 +1161,10 @@ static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hip
     case 11: return launch_cfg<128, 256, 2, 4, 2>(p, dma, splitk, stream);
     case 12: return launch_cfg<64, 256, 1, 4, 3>(p, dma, splitk, stream);
     case 13: return launch_cfg<256, 64, 4, 1, 3>(p, dma, splitk, stream);
+    case 14: return launch_halo_cfg<256, 64, 4, 2, 3>(p, splitk, stream);
+    case 15: return launch_halo_cfg<256, 128, 4, 2, 2>(p, splitk, stream);
+    case 16: return launch_halo_cfg<128, 64, 2, 2, 3>(p, splitk, stream);
+    case 17: return launch_halo_cfg<128, 128, 2, 2, 3>(p, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }
@@ -935,7 +1242,8 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
   static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
   for (int t = 0; t < SDMI_NUM_TILES; ++t) {
     const TileCfg& c = kTiles[t];
-    if (c.ns == 2 && t != 0 && t != 3 && t != 11) continue;           // the 2-stage twins of 3-stage tiles are never faster
+    if (tile_is_halo(t) && !halo_supported(p, c.bm)) continue;
+    if (c.ns == 2 && t != 0 && t != 3 && t != 11 && !tile_is_halo(t)) continue;   // the 2-stage twins of 3-stage tiles are never faster
     if (p.mode == EPI_GEGLU && !tile_tn_even(t)) continue;
     const long blocks = (long)cdiv(p.M, c.bm) * cdiv(p.N, c.bn);
     if ((long)c.bm > 2L * p.M && c.bm > 64) continue;                  // tile mostly padding
@@ -944,6 +1252,7 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
       if (sk > 1) {
         if (p.splitk != 0 || !can_split) break;                        // caller pinned the split
         if (nkt / sk < 4) break;                                       // >= 4 k-tiles per split
+        if (tile_is_halo(t) && (nkt / 9) % sk != 0) continue;          // halo tiles split at 64-channel chunk granularity
         if (blocks * (sk / 2 + 1) > 1536) break;                       // already plenty of blocks one step earlier
         if ((int64_t)sk * p.M * p.N > p.splitk_ws_floats) break;
       }
@@ -1082,7 +1391,8 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     } else {
       auto it = g_tuner.table.find(tkey);
       if (it != g_tuner.table.end() && (it->second.splitk == 1 || (can_split && (int64_t)it->second.splitk * p.M * p.N <= p.splitk_ws_floats)) &&
-          (p.mode != EPI_GEGLU || tile_tn_even(it->second.tile))) {
+          (p.mode != EPI_GEGLU || tile_tn_even(it->second.tile)) &&
+          (!tile_is_halo(it->second.tile) || halo_supported(p, kTiles[it->second.tile].bm))) {
         tile = it->second.tile; splitk = it->second.splitk;
       }
     }

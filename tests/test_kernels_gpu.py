@@ -28,7 +28,8 @@ def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
 
 
-ALL_TILES = list(range(14))     # include/sdmi.h: sdmi_igemm_desc.tile
+ALL_TILES = list(range(14))     # include/sdmi.h: sdmi_igemm_desc.tile (generic implicit GEMM)
+HALO_TILES = [14, 15, 16, 17]   # halo-staged 3x3 convolution: BM = 256, 256, 128, 128
 
 CONV_CASES = [
     # name, B, Hin, Win, c0, c1, N, ksize, stride, up
@@ -112,6 +113,61 @@ def test_igemm_splitk_inplace_residual(splitk, tile):
     K.igemm(a.to(DEV), wp, N, B, H, W, H, W, 3, 1, 0, bias=bias.to(DEV), residual=out2, out_f32=out2, splitk=splitk, tile=tile)
     torch.cuda.synchronize()
     assert torch.equal(out, out2)
+
+
+HALO_CASES = [
+    # name, B, H, W, c0, c1, N, splitk
+    ('h16', 2, 16, 16, 64, 0, 128, 1),
+    ('h16_cat', 1, 16, 16, 64, 128, 72, 1),          # skip concat (two sources), N tail inside a tile
+    ('h32', 1, 32, 32, 128, 0, 64, 1),
+    ('h32_split', 2, 32, 32, 256, 0, 320, 2),        # split-K at 64-channel chunk granularity (4 chunks -> 2 + 2)
+    ('h64', 2, 64, 64, 64, 0, 320, 1),               # the UNet's top level geometry (one chunk)
+    ('h64_deep', 1, 64, 64, 320, 0, 64, 5),          # 5 chunks, one per split
+    ('h16x32', 1, 16, 32, 192, 0, 128, 3),           # H != W
+]
+
+
+@pytest.mark.parametrize('case', HALO_CASES, ids=[c[0] for c in HALO_CASES])
+@pytest.mark.parametrize('tile', HALO_TILES)
+def test_conv3halo(case, tile):
+    """Halo-staged 3x3 conv (stride 1, pad 1; ResBlock convs, openaimodel.py:204,230) vs F.conv2d: every tile, image borders
+    (zero padding = out-of-range buffer loads), chunk changes (double-buffered halo), split-K, and the GroupNorm statistics."""
+    name, B, H, W, c0, c1, N, splitk = case
+    bm = 256 if tile in (14, 15) else 128
+    if (H * W) % bm or bm % W:
+        pytest.skip('tile rows do not fit this image')
+    g = _g(hash(name) % 1000)
+    Cin = c0 + c1
+    big = _rand16((B * H * W, Cin), g)
+    w = _rand16((N, Cin, 3, 3), g, 1.0 / math.sqrt(9 * Cin))
+    ref = _conv_ref(big[:, :c0], big[:, c0:] if c1 else None, w, B, H, W, 3, 1, 0)
+    M = B * H * W
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref2 = _nhwc(ref) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    out32 = torch.full((M, N), float('nan'), device=DEV)
+    big_d = big.to(DEV)
+    gn = None
+    if N % 4 == 0 and (H * W) % 32 == 0 and N // 32 >= 2:
+        acc0 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+        gn = [(acc0, N // 32, 0)]
+    K.igemm(big_d[:, :c0], wp, N, B, H, W, H, W, 3, 1, 0, a1=big_d[:, c0:] if c1 else None, bias=bias.to(DEV),
+            rowvec=rowvec.to(DEV), residual=resid.to(DEV), out_f32=out32, tile=tile, splitk=splitk, gn=gn)
+    torch.cuda.synchronize()
+    assert K.report(f'conv3halo {name} tile{tile} k{splitk}', out32, ref2, 3e-4) < 3e-4
+    if gn:
+        s_, ss_ = K.gn_acc_sums(acc0)
+        v = out32.cpu().double().reshape(B, H * W, 32, N // 32)
+        assert (s_ - v.sum((1, 3))).abs().max().item() < 2e-3
+        assert ((ss_ - (v ** 2).sum((1, 3))).abs() / (1.0 + (v ** 2).sum((1, 3)))).max().item() < 1e-5
+    # bit-identical on a second run (static schedule, fixed split order)
+    out2 = torch.full((M, N), float('nan'), device=DEV)
+    K.igemm(big_d[:, :c0], wp, N, B, H, W, H, W, 3, 1, 0, a1=big_d[:, c0:] if c1 else None, bias=bias.to(DEV),
+            rowvec=rowvec.to(DEV), residual=resid.to(DEV), out_f32=out2, tile=tile, splitk=splitk)
+    torch.cuda.synchronize()
+    assert torch.equal(out32, out2)
 
 
 @pytest.mark.parametrize('tile', [2, 5, 7, 8, 9, 12, 13])
