@@ -60,18 +60,23 @@ __device__ __forceinline__ float gelu_erf(float x) {
 __device__ __forceinline__ void wait_vmcnt_n(int n) {
   switch (n) {
 #define SDMI_VMCNT_CASE(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break
-    SDMI_VMCNT_CASE(0); SDMI_VMCNT_CASE(1); SDMI_VMCNT_CASE(2); SDMI_VMCNT_CASE(3); SDMI_VMCNT_CASE(4); SDMI_VMCNT_CASE(5);
-    SDMI_VMCNT_CASE(6); SDMI_VMCNT_CASE(7); SDMI_VMCNT_CASE(8); SDMI_VMCNT_CASE(9); SDMI_VMCNT_CASE(10); SDMI_VMCNT_CASE(11);
-    SDMI_VMCNT_CASE(12); SDMI_VMCNT_CASE(13); SDMI_VMCNT_CASE(14); SDMI_VMCNT_CASE(15); SDMI_VMCNT_CASE(16);
-    SDMI_VMCNT_CASE(18); SDMI_VMCNT_CASE(20); SDMI_VMCNT_CASE(22); SDMI_VMCNT_CASE(24); SDMI_VMCNT_CASE(26);
-    SDMI_VMCNT_CASE(28); SDMI_VMCNT_CASE(30);
+    SDMI_VMCNT_CASE(0); SDMI_VMCNT_CASE(1); SDMI_VMCNT_CASE(2); SDMI_VMCNT_CASE(3); SDMI_VMCNT_CASE(4);
+    SDMI_VMCNT_CASE(5); SDMI_VMCNT_CASE(6); SDMI_VMCNT_CASE(7); SDMI_VMCNT_CASE(8); SDMI_VMCNT_CASE(9);
+    SDMI_VMCNT_CASE(10); SDMI_VMCNT_CASE(11); SDMI_VMCNT_CASE(12); SDMI_VMCNT_CASE(13); SDMI_VMCNT_CASE(14);
+    SDMI_VMCNT_CASE(15); SDMI_VMCNT_CASE(16); SDMI_VMCNT_CASE(17); SDMI_VMCNT_CASE(18); SDMI_VMCNT_CASE(19);
+    SDMI_VMCNT_CASE(20); SDMI_VMCNT_CASE(21); SDMI_VMCNT_CASE(22); SDMI_VMCNT_CASE(23); SDMI_VMCNT_CASE(24);
+    SDMI_VMCNT_CASE(25); SDMI_VMCNT_CASE(26); SDMI_VMCNT_CASE(27); SDMI_VMCNT_CASE(28); SDMI_VMCNT_CASE(29);
+    SDMI_VMCNT_CASE(30); SDMI_VMCNT_CASE(31); SDMI_VMCNT_CASE(32); SDMI_VMCNT_CASE(33); SDMI_VMCNT_CASE(34);
+    SDMI_VMCNT_CASE(35); SDMI_VMCNT_CASE(36); SDMI_VMCNT_CASE(37); SDMI_VMCNT_CASE(38); SDMI_VMCNT_CASE(39);
+    SDMI_VMCNT_CASE(40); SDMI_VMCNT_CASE(41); SDMI_VMCNT_CASE(42); SDMI_VMCNT_CASE(43); SDMI_VMCNT_CASE(44);
+    SDMI_VMCNT_CASE(45); SDMI_VMCNT_CASE(46); SDMI_VMCNT_CASE(47); SDMI_VMCNT_CASE(48);
 #undef SDMI_VMCNT_CASE
-    default: __builtin_trap();
+    default: __builtin_trap();      // (vmcnt is a 6-bit field: 63 outstanding at most)
   }
 }
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N >= 0 && N <= 30 && (N <= 16 || N % 2 == 0), "add the literal");
+  static_assert(N >= 0 && N <= 48, "add the literal");
   wait_vmcnt_n(N);
 }
 
@@ -691,12 +696,17 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
   constexpr int HALO_BYTES = AHP * RPP * 128;
   constexpr int BSTAGE = BN * 128;
   constexpr int LDS_BYTES = 2 * HALO_BYTES + NS * BSTAGE;
-  constexpr int PA = (AHP + 7) / 8;                    // halo pieces of the NEXT chunk issued per tap (taps 0..7)
+  // The weight stream is what needs depth: every block reads every (chunk, tap) weight tile exactly once, and the blocks
+  // of an XCD walk the taps in step, so most weight tiles are first touches of that XCD's L2 (HBM / Infinity-Cache
+  // latency, ~1 us).  NS weight stages = NS - 1 taps of look-ahead; the halo of the NEXT chunk must be complete NS - 2
+  // taps before the chunk switch, so it is issued at taps 0 .. LASTA.
+  constexpr int LASTA = 10 - NS;
+  constexpr int PA = (AHP + LASTA) / (LASTA + 1);      // halo pieces of the NEXT chunk issued per tap (taps 0 .. LASTA)
   constexpr int KS = BK / 16;
   constexpr int G = (TM * TN >= 4) ? 1 : 2;            // k-steps per pipeline unit (>= 4 MFMAs of cover)
   constexpr int U = KS / G;
   constexpr int MPU = G * TM * TN;
-  static_assert(PB >= 1 && TM >= 1 && TN >= 1 && RPP % 16 == 0 && NS >= 2 && NS <= 3, "tile/wave shape");
+  static_assert(PB >= 1 && TM >= 1 && TN >= 1 && RPP % 16 == 0 && NS >= 2 && NS <= 9, "tile/wave shape");
   static_assert(LDS_BYTES <= 160 * 1024, "LDS budget");
 
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_BYTES];
@@ -809,18 +819,33 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
-  // ---- prologue: first halo, first NS - 1 weight tiles ------------------------------------------------------------
+  // DMA pieces this thread issues at tap t (t taken mod 9): halo pieces [a_lo, a_hi) of the next chunk, then PB weight
+  // pieces.  What may still be in flight when tile kt + 1 is needed = everything issued in the last NS - 2 taps.
+  auto a_lo = [](int t) { return t <= LASTA ? (t * PA < AHP ? t * PA : AHP) : AHP; };
+  auto a_hi = [](int t) { return t <= LASTA ? ((t + 1) * PA < AHP ? (t + 1) * PA : AHP) : AHP; };
+  auto in_flight_ok = [&](int t) {
+    int n = 0;
+    for (int d = 0; d < NS - 2; ++d) { const int tt = (t - d + 18) % 9; n += a_hi(tt) - a_lo(tt) + PB; }
+    return n;
+  };
+
+  // ---- prologue: the first halo, then the last NS - 1 taps of a virtual previous chunk (their halo pieces re-issue
+  // piece 0: same bytes, same issue counts as the steady state, so the vmcnt literals hold from the first tap on) ----
   const int kt_first = c_begin * 9, kt_last = c_end * 9 - 1;
   {
     const ChunkSrc cs = chunk_src(c_begin);
 #pragma unroll
     for (int q = 0; q < AHP; ++q) issue_halo(cs, 0, q);
 #pragma unroll
-    for (int s2 = 0; s2 < NS - 1; ++s2)
+    for (int s2 = 0; s2 < NS - 1; ++s2) {
+      const int vt = 9 - (NS - 1) + s2;
+#pragma unroll
+      for (int e = a_lo(vt); e < a_hi(vt); ++e) issue_halo(cs, 0, 0);
 #pragma unroll
       for (int q = 0; q < PB; ++q) issue_b(min(kt_first + s2, kt_last), s2, q);
+    }
   }
-  wait_vmcnt<(NS - 2) * PB>();
+  wait_vmcnt_n(in_flight_ok(8));
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   f16x8 fa[2][G][TM], fb[2][G][TN];
   int ab[TM];
@@ -843,9 +868,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
       int ab1[TM];
 #pragma unroll
       for (int i = 0; i < TM; ++i) ab1[i] = a_base(i, tap1 / 3, tap1 % 3, hb1);
-      const int a_lo = tap < 8 ? (tap * PA < AHP ? tap * PA : AHP) : AHP;
-      const int a_hi = tap < 8 ? ((tap + 1) * PA < AHP ? (tap + 1) * PA : AHP) : AHP;
-      const int na = a_hi - a_lo;                       // compile-time after unrolling
+      const int alo = a_lo(tap);
+      const int na = a_hi(tap) - alo;                   // compile-time after unrolling
       const int npieces = na + PB;
       const int ppu = (npieces + U - 2) / (U - 1);
       const int bt = min(kt + NS - 1, kt_last);
@@ -856,14 +880,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
           for (int g = 0; g < G; ++g) read_frags(ab, cur, (u + 1) * G + g, fa[(u + 1) & 1][g], fb[(u + 1) & 1][g]);
 #pragma unroll
           for (int e = u * ppu; e < (u + 1) * ppu && e < npieces; ++e) {
-            if (e < na) issue_halo(csn, hb ^ 1, a_lo + e);        // halo pieces first: older than this tap's weights
+            if (e < na) issue_halo(csn, hb ^ 1, alo + e);         // halo pieces first: older than this tap's weights
             else issue_b(bt, nxt, e - na);
           }
         } else {
-          // allowed in flight: what the last NS - 2 taps issued (this tap's pieces for NS = 3): weight tile kt + 1 --
-          // and, at tap 8, the whole next halo (issued at taps <= 7) -- has landed for this wave; the barrier makes it
-          // everybody's, and tells everybody this tile's LDS reads are done
-          if (NS == 3) wait_vmcnt_n(na + PB); else wait_vmcnt_n(0);
+          // allowed in flight: what the last NS - 2 taps issued.  Weight tile kt + 1 -- and, at tap 8, the whole next halo
+          // (issued at taps <= LASTA) -- has landed for this wave; the barrier makes it everybody's, and tells everybody
+          // this tile's LDS reads are done
+          wait_vmcnt_n(in_flight_ok(tap));
           asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #pragma unroll
           for (int g = 0; g < G; ++g) read_frags(ab1, cur1, g, fa[0][g], fb[0][g]);
@@ -1136,10 +1160,10 @@ static const TileCfg kTiles[SDMI_NUM_TILES] = {
     {64, 256, 1, 4, 3},    // 12  4 waves, 2x2, 120 KB (small M, wide N: one A tile shared by the 4 waves)
     {256, 64, 4, 1, 3},    // 13  4 waves, 2x2, 120 KB (large M, N = 5 x 64)
     // halo-staged 3x3 convolution (conv3halo_kernel): tiles of whole image rows
-    {256, 64, 4, 2, 3},    // 14  8 waves, 2x1 per wave
-    {256, 128, 4, 2, 2},   // 15  8 waves, 2x2
-    {128, 64, 2, 2, 3},    // 16  4 waves, 2x1
-    {128, 128, 2, 2, 3},   // 17  4 waves, 2x2
+    {256, 64, 4, 2, 5},    // 14  8 waves, 2x1 per wave, 152 KB
+    {256, 128, 4, 2, 3},   // 15  8 waves, 2x2, 160 KB
+    {128, 64, 2, 2, 8},    // 16  4 waves, 2x1, 136 KB
+    {128, 128, 2, 2, 5},   // 17  4 waves, 2x2, 152 KB
 };
 constexpr int SDMI_FIRST_HALO_TILE = 14;
 static inline bool tile_is_halo(int t) { return t >= SDMI_FIRST_HALO_TILE; }
@@ -1161,10 +1185,10 @@ static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hip
     case 11: return launch_cfg<128, 256, 2, 4, 2>(p, dma, splitk, stream);
     case 12: return launch_cfg<64, 256, 1, 4, 3>(p, dma, splitk, stream);
     case 13: return launch_cfg<256, 64, 4, 1, 3>(p, dma, splitk, stream);
-    case 14: return launch_halo_cfg<256, 64, 4, 2, 3>(p, splitk, stream);
-    case 15: return launch_halo_cfg<256, 128, 4, 2, 2>(p, splitk, stream);
-    case 16: return launch_halo_cfg<128, 64, 2, 2, 3>(p, splitk, stream);
-    case 17: return launch_halo_cfg<128, 128, 2, 2, 3>(p, splitk, stream);
+    case 14: return launch_halo_cfg<256, 64, 4, 2, 5>(p, splitk, stream);
+    case 15: return launch_halo_cfg<256, 128, 4, 2, 3>(p, splitk, stream);
+    case 16: return launch_halo_cfg<128, 64, 2, 2, 8>(p, splitk, stream);
+    case 17: return launch_halo_cfg<128, 128, 2, 2, 5>(p, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }

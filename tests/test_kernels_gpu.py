@@ -150,7 +150,7 @@ def test_conv3halo(case, tile):
     out32 = torch.full((M, N), float('nan'), device=DEV)
     big_d = big.to(DEV)
     gn = None
-    if N % 4 == 0 and (H * W) % 32 == 0 and N // 32 >= 2:
+    if N % 32 == 0 and (H * W) % 32 == 0 and N // 32 >= 2:
         acc0 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
         gn = [(acc0, N // 32, 0)]
     K.igemm(big_d[:, :c0], wp, N, B, H, W, H, W, 3, 1, 0, a1=big_d[:, c0:] if c1 else None, bias=bias.to(DEV),
