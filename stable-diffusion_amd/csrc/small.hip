@@ -141,49 +141,6 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* h, const flo
   }
 }
 
-// The same conv with the weights staged in LDS once per block (Cout * 9 * Cin floats: 46 KB for SD's 320 -> 4) and
-// PIX pixels per block, one wave per pixel at a time, lane = channel (stride 64): the kernel above re-reads all weights
-// from L2 for every pixel (377 MB of cache traffic for one 64x64 call, 64 us); this one reads them 8192 / PIX times less.
-constexpr int CO_PIX = 32;
-__global__ void __launch_bounds__(256) conv_out_lds_kernel(const float* h, const float* w, const float* bias, float* out, int B,
-                                                           int H, int W, int Cin, int Cout) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];        // [Cout * 9][Cin]
-  const int nw = Cout * 9 * Cin;
-  for (int i = threadIdx.x * 4; i < nw; i += 1024) *(f32x4*)(wl + i) = *(const f32x4*)(w + i);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int M = B * H * W;
-  for (int pi = wave; pi < CO_PIX; pi += 4) {
-    const int m = blockIdx.x * CO_PIX + pi;              // wave-uniform
-    if (m >= M) break;
-    const int b = m / (H * W), rem = m - b * H * W, y = rem / W, x = rem - y * W;
-    float acc[CO_MAXN];
-#pragma unroll
-    for (int n = 0; n < CO_MAXN; ++n) acc[n] = 0.f;
-    for (int tap = 0; tap < 9; ++tap) {
-      const int ky = tap / 3, kx = tap - ky * 3;
-      const int iy = y + ky - 1, ix = x + kx - 1;
-      if (iy < 0 || iy >= H || ix < 0 || ix >= W) continue;
-      const float* src = h + ((size_t)(b * H + iy) * W + ix) * Cin;
-      for (int c = lane; c < Cin; c += 64) {
-        const float xv = src[c];
-#pragma unroll
-        for (int n = 0; n < CO_MAXN; ++n)
-          if (n < Cout) acc[n] = fmaf(wl[(n * 9 + tap) * Cin + c], xv, acc[n]);
-      }
-    }
-#pragma unroll
-    for (int n = 0; n < CO_MAXN; ++n) {
-      if (n < Cout) {
-        float v = acc[n];
-#pragma unroll
-        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-        if (lane == 0) out[(((size_t)b * Cout + n) * H + y) * W + x] = v + (bias ? bias[n] : 0.f);
-      }
-    }
-  }
-}
-
 // ---- packing -------------------------------------------------------------------------------------------
 __global__ void pack_conv_kernel(const float* w, f16* dst, int O, int I, int KH, int KW) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -383,11 +340,9 @@ int launch_conv_out(const float* h, const float* w, const float* bias, float* ou
                     hipStream_t s) {
   SDMI_CHECK(Cout <= CO_MAXN && Cin % 4 == 0, "conv_out: out_channels <= 8, Cin % 4 == 0");
   ProfScope ps("conv_out_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
-  const size_t wbytes = (size_t)Cout * 9 * Cin * sizeof(float);
-  if (wbytes <= 64 * 1024)
-    hipLaunchKernelGGL(conv_out_lds_kernel, dim3(cdiv(B * H * W, CO_PIX)), dim3(256), wbytes, s, h, w, bias, out, B, H, W, Cin, Cout);
-  else
-    hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+  // (an LDS-resident-weights variant, 32 pixels per block, was measured at 169 us vs 64 us: one wave per pixel keeps 1024
+  // independent waves in flight, which this latency-bound fp32 kernel needs more than it needs fewer weight re-reads)
+  hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
