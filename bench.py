@@ -321,12 +321,12 @@ def main():
                 table.sort(key=lambda r: -r['ms'])
                 # The implicit-GEMM kernel is ONE template (csrc/igemm.hip) launched in several tile instantiations
                 # chosen per shape by the tuning table: the dominant kernel is that family; its instantiations are listed.
-                fam = [r for r in table if r['name'].startswith('igemm')]
-                dom = {'name': 'igemm_kernel<BM,BN,waves,stages,kind> (all instantiations)',
+                fam = [r for r in table if r['name'].startswith(('igemm', 'conv3halo'))]
+                dom = {'name': 'igemm_kernel / conv3halo_kernel (one GEMM core + epilogue, all tile instantiations)',
                        'launches': sum(r['launches'] for r in fam), 'ms': sum(r['ms'] for r in fam),
                        'flops': sum(r['flops'] for r in fam), 'bytes': sum(r['bytes'] for r in fam)}
                 top = fam[0]
-                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'attn'))]
+                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'conv3halo', 'attn'))]
                 ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
                 cls = lambda r: {'name': r['name'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
                                  'tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if r['flops'] else None,
@@ -347,7 +347,7 @@ def main():
                     if mfma else None,
                 }
                 # second entry: the dominant HBM-bound kernel class (norms / reduce / casts), against the HBM peak
-                hbm = [r for r in table if not r['name'].startswith(('igemm', 'attn'))]
+                hbm = [r for r in table if not r['name'].startswith(('igemm', 'conv3halo', 'attn'))]
                 if hbm:
                     h = hbm[0]
                     gbs = h['bytes'] / (h['ms'] * 1e-3) / 1e9

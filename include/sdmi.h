@@ -185,7 +185,8 @@ typedef struct sdmi_igemm_desc {
                                            2 64x64/4/2, 3 256x128/8/2, 4 128x64/4/3, 5 64x64/4/3, 6 256x128/8/3, 7 128x128/4/3,
                                            8 64x128/4/3, 9 128x128/8/3, 10 64x64/4/4, 11 128x256/8/2, 12 64x256/4/3, 13 256x64/4/3;
                                            halo-staged 3x3 conv (stride 1, pad 1, width 16/32/64, whole-row tiles):
-                                           14 256x64/8/5, 15 256x128/8/3, 16 128x64/4/8, 17 128x128/4/5 */
+                                           14 256x64/8/5, 15 256x128/8/3, 16 128x64/4/8, 17 128x128/4/5;
+                                           deep rings (generic): 18 64x64/4/8, 19 64x128/4/6, 20 128x64/4/6, 21 128x128/8/4 */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
   int32_t asym_pad;                     /* 3x3 only: 0 = zero pad 1 on every side; 1 = pad right/bottom only, i.e.
                                            F.pad(x,(0,1,0,1)) + conv(padding=0) of the VAE Downsample (model.py:72-76) */

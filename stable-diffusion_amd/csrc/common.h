@@ -98,9 +98,12 @@ struct IGemmParams {
   // filled by the launcher: ceil(2^40 / (Hout*Wout)) and ceil(2^40 / Wout) for the kernel's division-free row split
   unsigned long long magic_hw = 0, magic_w = 0, magic_w2 = 0;   // (magic_w2: Wout + 2, halo-staged conv)
   int log2w = 0;
+  // halo-staged conv geometry (launcher): output rows per image in a tile, images per tile, log2(pixels per image part)
+  int halo_thi = 0, halo_ipt = 1, log2_tpi = 30;
+  unsigned long long magic_hpi = 0;
 };
 
-constexpr int SDMI_NUM_TILES = 18;   // tile ids 0 .. 17 (14..17: halo-staged 3x3 conv), see kTiles in igemm.hip and include/sdmi.h
+constexpr int SDMI_NUM_TILES = 22;   // tile ids 0 .. 21 (14..17: halo-staged 3x3 conv), see kTiles in igemm.hip and include/sdmi.h
 struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes the tuning table's choice)
   int tile = -1;          // -1 auto (tuning table, then heuristic); else a tile id
   int dma = -1;           // -1 default, 0 register-staged loads, 1 global_load_lds

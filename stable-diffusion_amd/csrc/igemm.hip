@@ -736,11 +736,13 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
   const int l31 = lane & 31, lg = lane >> 5;
   const int rsw = (l31 >> 1) & 7;
 
+  // tile geometry: BM <= H*W: TH = BM / W rows of one image; BM > H*W: BM / (H*W) whole images (each with its own halo)
   const int W = p.Wout, H = p.Hout, HW = H * W, W2 = W + 2, ld = p.lda0;
   const int bimg = m0 / HW;
-  const int y0 = (m0 - bimg * HW) >> p.log2w;
-  const int TH = BM >> p.log2w;
-  const int HP = (TH + 2) * W2;
+  const int THI = p.halo_thi;                     // output rows per image inside the tile
+  const int HPI = (THI + 2) * W2;                 // halo pixels per image
+  const int y0 = p.halo_ipt > 1 ? 0 : (m0 - bimg * HW) >> p.log2w;
+  const int HP = p.halo_ipt * HPI;
   constexpr int OOB = (int)0x80000000;
 
   // per-lane source byte offset of every halo piece (constant over the chunks: the chunk moves the scalar offset)
@@ -748,10 +750,11 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
 #pragma unroll
   for (int q = 0; q < AHP; ++q) {
     const int hp = q * RPP + lrow;
-    const int hy = fast_div(hp, p.magic_w2), hx = hp - hy * W2;
+    const int ip = fast_div(hp, p.magic_hpi), hr = hp - ip * HPI;
+    const int hy = fast_div(hr, p.magic_w2), hx = hr - hy * W2;
     const int y = y0 + hy - 1, x = hx - 1;
     const bool valid = hp < HP && y >= 0 && y < H && x >= 0 && x < W;
-    hvoff[q] = valid ? (((bimg * H + y) * W + x) * ld + gch * 8) * 2 : OOB;
+    hvoff[q] = valid ? ((((bimg + ip) * H + y) * W + x) * ld + gch * 8) * 2 : OOB;
   }
   int b_off[PB];
 #pragma unroll
@@ -764,7 +767,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     const int ml = wm * WTM + i * 32 + l31;
-    hr0[i] = (ml >> p.log2w) * W2 + (ml & (W - 1));
+    const int ip = ml >> p.log2_tpi, mr = ml & ((1 << p.log2_tpi) - 1);     // image inside the tile, pixel inside the image part
+    hr0[i] = ip * HPI + (mr >> p.log2w) * W2 + (mr & (W - 1));
   }
   const int b_lds = 2 * HALO_BYTES + (wn * WTN + l31) * 128;
 
@@ -1102,9 +1106,13 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
 // halo-staged 3x3 convolution: supported iff stride 1, pad 1, no upsampling, power-of-two width 16..64 and tiles of whole
 // image rows that do not straddle samples
 static bool halo_supported(const IGemmParams& p, int bm) {
-  const int W = p.Wout;
-  return p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.up && p.Hin == p.Hout && p.Win == p.Wout && W >= 16 && W <= 64 &&
-         (W & (W - 1)) == 0 && bm % W == 0 && (p.Hout * p.Wout) % bm == 0;
+  const int W = p.Wout, HW = p.Hout * p.Wout;
+  if (!(p.ksize == 3 && p.stride == 1 && p.pad == 1 && !p.up && p.Hin == p.Hout && p.Win == p.Wout && W >= 8 && W <= 64 &&
+        (W & (W - 1)) == 0 && bm % W == 0))
+    return false;
+  const int cap = (((bm / 64 + 2) * 66 + bm / 4 - 1) / (bm / 4)) * (bm / 4);    // halo rows an LDS buffer holds (AHP * RPP)
+  if (bm <= HW) return HW % bm == 0 && (bm / W + 2) * (W + 2) <= cap;
+  return bm % HW == 0 && p.M % bm == 0 && (bm / HW) * (p.Hout + 2) * (W + 2) <= cap;    // whole images per tile
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
@@ -1121,6 +1129,16 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   q.magic_w2 = div_magic(p.Wout + 2);
   q.log2w = 0;
   while ((1 << q.log2w) < p.Wout) ++q.log2w;
+  {
+    const int HW = p.Hout * p.Wout;
+    q.halo_ipt = BM <= HW ? 1 : BM / HW;
+    q.halo_thi = BM <= HW ? BM / p.Wout : p.Hout;
+    q.magic_hpi = div_magic((q.halo_thi + 2) * (p.Wout + 2));
+    const int tpi = q.halo_thi * p.Wout;             // output pixels per image part: a power of two when halo_ipt > 1
+    q.log2_tpi = 0;
+    while ((1 << q.log2_tpi) < tpi) ++q.log2_tpi;
+    if (q.halo_ipt == 1) q.log2_tpi = 30;            // one image: every row of the tile belongs to part 0
+  }
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
   static const int by_shape = env_int("SDMI_PROF_SHAPES", 0);
@@ -1164,9 +1182,14 @@ static const TileCfg kTiles[SDMI_NUM_TILES] = {
     {256, 128, 4, 2, 3},   // 15  8 waves, 2x2, 160 KB
     {128, 64, 2, 2, 8},    // 16  4 waves, 2x1, 136 KB
     {128, 128, 2, 2, 5},   // 17  4 waves, 2x2, 152 KB
+    // generic again: deep LDS-DMA rings for the weight-streaming shapes (small M, K in the thousands: every weight tile is a
+    // first touch of the XCD's L2, so the ring has to cover HBM latency, ~1 us = 5+ k-tiles of MFMA work)
+    {64, 64, 2, 2, 8},     // 18  1x1, 128 KB
+    {64, 128, 2, 2, 6},    // 19  1x2, 144 KB
+    {128, 64, 2, 2, 6},    // 20  2x1, 144 KB
+    {128, 128, 4, 2, 4},   // 21  8 waves, 1x2, 128 KB
 };
-constexpr int SDMI_FIRST_HALO_TILE = 14;
-static inline bool tile_is_halo(int t) { return t >= SDMI_FIRST_HALO_TILE; }
+static inline bool tile_is_halo(int t) { return t >= 14 && t <= 17; }
 static inline bool tile_tn_even(int t) { return (kTiles[t].bn / kTiles[t].wn / 32) % 2 == 0; }
 
 static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
@@ -1189,6 +1212,10 @@ static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hip
     case 15: return launch_halo_cfg<256, 128, 4, 2, 3>(p, splitk, stream);
     case 16: return launch_halo_cfg<128, 64, 2, 2, 8>(p, splitk, stream);
     case 17: return launch_halo_cfg<128, 128, 2, 2, 5>(p, splitk, stream);
+    case 18: return launch_cfg<64, 64, 2, 2, 8>(p, dma, splitk, stream);
+    case 19: return launch_cfg<64, 128, 2, 2, 6>(p, dma, splitk, stream);
+    case 20: return launch_cfg<128, 64, 2, 2, 6>(p, dma, splitk, stream);
+    case 21: return launch_cfg<128, 128, 4, 2, 4>(p, dma, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }

@@ -28,7 +28,7 @@ def _nhwc(x):  # [B,C,H,W] -> [B*H*W, C]
     return x.permute(0, 2, 3, 1).reshape(B * H * W, C).contiguous()
 
 
-ALL_TILES = list(range(14))     # include/sdmi.h: sdmi_igemm_desc.tile (generic implicit GEMM)
+ALL_TILES = list(range(14)) + [18, 19, 20, 21]     # include/sdmi.h: sdmi_igemm_desc.tile (generic implicit GEMM)
 HALO_TILES = [14, 15, 16, 17]   # halo-staged 3x3 convolution: BM = 256, 256, 128, 128
 
 CONV_CASES = [
@@ -124,6 +124,9 @@ HALO_CASES = [
     ('h64', 2, 64, 64, 64, 0, 320, 1),               # the UNet's top level geometry (one chunk)
     ('h64_deep', 1, 64, 64, 320, 0, 64, 5),          # 5 chunks, one per split
     ('h16x32', 1, 16, 32, 192, 0, 128, 3),           # H != W
+    ('h8_2img', 2, 8, 8, 128, 0, 64, 2),             # tiles of whole images (BM = 128: two 8x8 images, each with its own halo)
+    ('h8_4img', 4, 8, 8, 64, 64, 128, 1),            # BM = 256: four images per tile
+    ('h16_2img', 2, 16, 8, 64, 0, 96, 1),            # 16x8 images: BM = 128 is one image, BM = 256 two
 ]
 
 
@@ -134,7 +137,8 @@ def test_conv3halo(case, tile):
     (zero padding = out-of-range buffer loads), chunk changes (double-buffered halo), split-K, and the GroupNorm statistics."""
     name, B, H, W, c0, c1, N, splitk = case
     bm = 256 if tile in (14, 15) else 128
-    if (H * W) % bm or bm % W:
+    fits = (H * W) % bm == 0 if bm <= H * W else (bm % (H * W) == 0 and (B * H * W) % bm == 0)
+    if not fits or bm % W:
         pytest.skip('tile rows do not fit this image')
     g = _g(hash(name) % 1000)
     Cin = c0 + c1
