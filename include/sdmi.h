@@ -236,6 +236,14 @@ int sdmi_k_pointwise_nchw(const float* x, const float* w, const float* bias, flo
                           float in_scale, void* stream);
 int sdmi_k_softmax_rows(const float* S, void* P_f16, int rows, int cols, float scale, void* stream);
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst_f16, float* bdst, int N, int K, void* stream);
+/* fp16 range guard (debug; also SDMI_CHECK_RANGE=1 in the environment): after every launch that writes fp16 activations
+ * (MFMA operands: GroupNorm / LayerNorm outputs, q / k / v^T, GEGLU, attention output, fp16 copies of the residual
+ * stream) the buffer is scanned.  The reference has the same exposure under torch.autocast (scripts/txt2img.py:283);
+ * this makes an overflow visible per launch.  Synchronises the stream after each launch: never on in a timed run.
+ * sdmi_range_check(enable) also clears the counters; sdmi_range_report writes
+ * {"over_6e4": n, "nonfinite": m, "max_abs": x, "first": "<first offending kernel class>"}. */
+int sdmi_range_check(int enable);
+int sdmi_range_report(char* json_buf, int json_buf_len);
 /* In-situ tuning of the implicit-GEMM tile / split-K choice (no reference counterpart: the reference delegates to
  * MIOpen / hipBLASLt heuristics).  begin -> for r in rounds: sdmi_tune_round(r), run the workloads -> end: every
  * auto-configured GEMM launch between begin and end runs candidate (r mod #candidates) of its shape, timed with HIP

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libsdmi.so')
-SOURCES = ['igemm.hip', 'conv3gn.hip', 'attn.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
+SOURCES = ['igemm.hip', 'range.hip', 'conv3gn.hip', 'attn.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable']
 

@@ -315,6 +315,15 @@ int sdmi_k_pack_split3(const float* w, void* dst, int N, int K, void* stream) {
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst, float* bdst, int N, int K, void* stream) {
   return launch_pack_geglu(w, bias, (f16*)wdst, bdst, N, K, (hipStream_t)stream);
 }
+int sdmi_range_check(int enable) { return range_check_set(enable); }
+int sdmi_range_report(char* buf, int buflen) {
+  SDMI_CHECK(buf && buflen > 1, "null buffer");
+  std::string js;
+  if (range_report(&js)) return -1;
+  SDMI_CHECK((int)js.size() + 1 <= buflen, "range report buffer too small");
+  memcpy(buf, js.c_str(), js.size() + 1);
+  return 0;
+}
 int sdmi_tune_begin(void) { return tune_begin(); }
 int sdmi_tune_round(int r) { return tune_round(r); }
 int sdmi_tune_end(const char* path, int* n_keys) { return tune_end(path, n_keys); }

@@ -242,7 +242,13 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
 
 }  // namespace
 
+static int launch_attention_impl(const AttnParams& p, hipStream_t stream);
 int launch_attention(const AttnParams& p, hipStream_t stream) {
+  const int rc = launch_attention_impl(p, stream);
+  if (rc == 0 && range_check_enabled()) return range_scan("attention output", p.out, (int64_t)p.BH * p.nq * p.d, stream);
+  return rc;
+}
+static int launch_attention_impl(const AttnParams& p, hipStream_t stream) {
   SDMI_CHECK(p.BH > 0 && p.nq > 0 && p.nkv > 0 && p.heads > 0 && p.BH % p.heads == 0, "bad attention shape");
   SDMI_CHECK(p.nkv_pad % 8 == 0 && p.nkv_pad >= p.nkv, "nkv_pad must be a multiple of 8 and >= nkv");
   SDMI_CHECK(!p.causal || p.nq == p.nkv, "causal attention needs nq == nkv");

@@ -110,6 +110,12 @@ struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes
 };
 
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream);
+// fp16 range guard (range.hip, debug): scan an fp16 activation buffer a launch just wrote; see SDMI_CHECK_RANGE
+bool range_check_enabled();
+int range_check_set(int enable);
+int range_scan(const char* what, const f16* p, int64_t n, hipStream_t stream);
+int range_report(std::string* json);
+
 // in-situ tuning (igemm.hip): begin a collection run, select the candidate index for the following launches, end it
 // (folds the timings into the table and writes it to `path`, or next to libsdmi.so when NULL)
 int tune_begin();

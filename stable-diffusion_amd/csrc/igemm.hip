@@ -1472,6 +1472,16 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   }
   if (ev0) SDMI_HIP_OK(hipEventRecord(ev0, stream));
   const int rc = launch_tile(tile, p, dma, splitk, stream);
+  if (rc == 0 && range_check_enabled()) {          // debug: fp16 outputs of this GEMM (MFMA operands of the next)
+    const char* what = p.mode == EPI_GEGLU ? "igemm GEGLU output" : (p.mode == EPI_HEADS ? "igemm q/k/v^T" : "igemm fp16 output");
+    if (p.mode == EPI_HEADS) {
+      for (int sg = 0; sg < p.N / p.segC; ++sg)
+        if (range_scan(what, p.seg_dst[sg], p.seg_kind[sg] == 0 ? (int64_t)p.M * p.segC : (int64_t)p.B * p.segC * p.ntok_pad, stream)) return -1;
+    } else if (p.out_f16) {
+      if (range_scan(what, p.out_f16, (int64_t)(p.M - 1) * p.ldo + (p.mode == EPI_GEGLU ? p.N / 2 : p.N), stream)) return -1;
+    }
+    if (p.ln_out && range_scan("LayerNorm output", p.ln_out, (int64_t)p.M * p.N, stream)) return -1;
+  }
   if (ev0) {
     SDMI_HIP_OK(hipEventRecord(ev1, stream));
     std::lock_guard<std::mutex> lk(g_tuner.mu);

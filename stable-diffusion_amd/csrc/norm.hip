@@ -231,6 +231,11 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
       hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p);
   }
   SDMI_HIP_OK(hipGetLastError());
+  if (range_check_enabled()) {
+    const int64_t nel = (int64_t)p.B * p.HW * C;
+    if (range_scan("GroupNorm fp16 output", p.out_f16, nel, stream)) return -1;
+    if (range_scan("GroupNorm raw fp16 copy of the residual stream (1x1 skip conv operand)", p.raw_f16, nel, stream)) return -1;
+  }
   return 0;
 }
 
@@ -251,6 +256,7 @@ int launch_cast_f16(const float* x, f16* out, f16* out_lo, int64_t n, hipStream_
   ProfScope ps("cast_f16", 0.0, (double)n * 6.0, stream);
   hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, out, out_lo, n4);
   SDMI_HIP_OK(hipGetLastError());
+  if (range_check_enabled() && range_scan("fp16 cast of the residual stream / context", out, n, stream)) return -1;
   return 0;
 }
 

@@ -188,6 +188,34 @@ def test_packed_weight_blob_round_trip(tmp_path):
         UNetModelHIP(**kw).cuda().load_packed(bad)
 
 
+def test_fp16_range_guard_reports_the_first_overflowing_operand():
+    """SDMI_CHECK_RANGE / debug.range_check: clean on the synthetic weights; with a GEGLU projection scaled x3000 (an
+    outlier layer, as real checkpoints have) the GEGLU output leaves the fp16 range and the report names that operand."""
+    from stable_diffusion_amd import UNetModelHIP, debug
+    m, sd = _model('tiny', 0)
+    x, t, ctx = make_inputs(TINY, 2, 16, 16, seed=3)
+    ref = m(x.cuda(), t.cuda(), context=ctx.cuda())
+    debug.range_check(True)
+    try:
+        out = m(x.cuda(), t.cuda(), context=ctx.cuda())
+        rep = debug.range_report()
+        print('[range guard] clean model:', rep, flush=True)
+        assert torch.equal(out, ref)                                  # the guard only looks
+        assert rep['over_6e4'] == 0 and rep['nonfinite'] == 0 and 1.0 < rep['max_abs'] < 6.0e4 and rep['first'] == ''
+        hot = UNetModelHIP(**TINY.ref_kwargs())
+        sd2 = {k: v.clone() for k, v in sd.items()}
+        sd2['input_blocks.1.1.transformer_blocks.0.ff.net.0.proj.weight'] *= 3000.0
+        hot.load_state_dict(sd2, strict=True)
+        hot = hot.cuda()
+        debug.range_check(True)                                       # clears the counters
+        hot(x.cuda(), t.cuda(), context=ctx.cuda())
+        rep = debug.range_report()
+        print('[range guard] GEGLU proj x3000:', rep, flush=True)
+        assert rep['over_6e4'] + rep['nonfinite'] > 0 and rep['first'] == 'igemm GEGLU output'
+    finally:
+        debug.range_check(False)
+
+
 def test_refuses_cpu_and_bad_config():
     from stable_diffusion_amd import UNetModelHIP
     m, sd = _model('tiny', 0)
