@@ -23,7 +23,7 @@ namespace {
 
 constexpr int KVT = 64;
 
-template <int D, int NW>
+template <int D, int NW, bool CAUSAL>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
   constexpr int DKS = (D + 15) / 16;   // k-steps of 16 over the head dim (QK^T)
   constexpr int DVT = (D + 31) / 32;   // 32-row tiles over the head dim (PV)
@@ -138,10 +138,13 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
         s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
       }
     }
-    // ---- mask keys beyond nkv (last tile only) ----
+    // ---- mask keys beyond nkv (last tile only; every tile when causal) ----
+    // A real, wave-uniform branch: if-converted into 64 compares + selects per tile it was a third of the loop's
+    // instructions (round-1 ISA) although only the last tile of a non-causal call has anything to mask.
     const int kv0 = t * KVT;
-    if (kv0 + KVT > p.nkv || p.causal) {
-      const int qlim = p.causal ? (q0 + l31) : 0x7fffffff;       // causal: this lane's query sees keys <= its own index
+    if (CAUSAL || kv0 + KVT > p.nkv) {
+      asm volatile("; masked tile" ::: "memory");                // (keeps the compiler from speculating the block)
+      const int qlim = CAUSAL ? (q0 + l31) : 0x7fffffff;         // causal: this lane's query sees keys <= its own index
 #pragma unroll
       for (int kvb = 0; kvb < KVT / 32; ++kvb)
 #pragma unroll
@@ -158,22 +161,28 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvb][r]);
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float m_new = fmaxf(m_run, mx * sc);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
+    // The running maximum stops growing after the first few tiles: when it did not move for ANY query of this wave the
+    // rescale factor is exactly 2^0 = 1 for every lane, and skipping the multiplies is bit-identical.
+    if (__any(m_new > m_run)) {
+      asm volatile("; rescale" ::: "memory");
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
     float psum = 0.f;
 #pragma unroll
     for (int kvb = 0; kvb < KVT / 32; ++kvb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kvb][r], sc, -m_new));
+        const float pv = __builtin_amdgcn_exp2f(fmaf(s[kvb][r], sc, -m_run));
         s[kvb][r] = pv;
         psum += pv;
       }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < DVT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    l_run += psum;
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -233,9 +242,12 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
   dim3 grid(cdiv(p.nq, 32 * nw), p.BH);
   static const std::string pname = std::string("attn_d") + std::to_string(D);
   ProfScope ps(pname.c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
-  if (nw == 8) hipLaunchKernelGGL((attn_kernel<D, 8>), grid, dim3(512), 0, stream, p);
-  else if (nw == 4) hipLaunchKernelGGL((attn_kernel<D, 4>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((attn_kernel<D, 2>), grid, dim3(128), 0, stream, p);
+  if (p.causal) {          // the text encoder's 77-token self-attention: one configuration is enough
+    if constexpr (D == 32 || D == 64 || D == 128) hipLaunchKernelGGL((attn_kernel<D, 2, true>), dim3(cdiv(p.nq, 64), p.BH), dim3(128), 0, stream, p);
+    else return fail("causal attention is instantiated for head dims 32 / 64 / 128");
+  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<D, 8, false>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) hipLaunchKernelGGL((attn_kernel<D, 4, false>), grid, dim3(256), 0, stream, p);
+  else hipLaunchKernelGGL((attn_kernel<D, 2, false>), grid, dim3(128), 0, stream, p);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

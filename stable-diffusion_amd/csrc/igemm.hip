@@ -1244,7 +1244,7 @@ class Tuner {
   bool loaded = false, collecting = false;
   int round = 0;
   std::vector<TuneRec> recs;
-  std::map<TuneKey, std::vector<std::pair<TuneChoice, std::pair<double, int>>>> stats;   // per candidate: (sum us, n)
+  std::map<TuneKey, std::vector<std::pair<TuneChoice, std::vector<float>>>> stats;   // per candidate: the samples (us)
   std::vector<hipEvent_t> pool;
 
   static std::string default_path() {
@@ -1294,7 +1294,10 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
   for (int t = 0; t < SDMI_NUM_TILES; ++t) {
     const TileCfg& c = kTiles[t];
     if (tile_is_halo(t) && !halo_supported(p, c.bm)) continue;
-    if (c.ns == 2 && t != 0 && t != 3 && t != 11 && !tile_is_halo(t)) continue;   // the 2-stage twins of 3-stage tiles are never faster
+    // never chosen by any of the round-2 collection runs (profiles/tune_candidates_r02.txt): the 2-stage twins of the
+    // 3-stage tiles, 128x128 / 256x128 with 2 stages, and the 64x256 / 256x64 4-wave tiles -- fewer candidates = more
+    // samples per candidate
+    if ((c.ns == 2 && t != 11 && !tile_is_halo(t)) || t == 12 || t == 13) continue;
     if (p.mode == EPI_GEGLU && !tile_tn_even(t)) continue;
     const long blocks = (long)cdiv(p.M, c.bm) * cdiv(p.N, c.bn);
     if ((long)c.bm > 2L * p.M && c.bm > 64) continue;                  // tile mostly padding
@@ -1335,7 +1338,7 @@ static int tune_drain() {
     SDMI_HIP_OK(hipEventSynchronize(r.e1));
     SDMI_HIP_OK(hipEventElapsedTime(&ms, r.e0, r.e1));
     auto& v = g_tuner.stats[r.key];
-    if ((int)v.size() > r.cand) { v[r.cand].second.first += ms * 1e3; v[r.cand].second.second += 1; }
+    if ((int)v.size() > r.cand) v[r.cand].second.push_back(ms * 1e3f);
     g_tuner.pool.push_back(r.e0); g_tuner.pool.push_back(r.e1);
   }
   g_tuner.recs.clear();
@@ -1346,10 +1349,19 @@ int tune_end(const char* path, int* n_keys) {
   if (!g_tuner.collecting) return fail("sdmi_tune_end without sdmi_tune_begin");
   if (tune_drain()) return -1;
   g_tuner.collecting = false;
+  // score of a candidate = median of its samples (in-situ samples carry launch-order and cache-state outliers; the mean of
+  // 2-3 of them flipped choices from run to run)
+  auto score = [](std::vector<float> v) -> double {
+    if (v.empty()) return 1e30;
+    std::sort(v.begin(), v.end());
+    return v.size() % 2 ? v[v.size() / 2] : 0.5 * (v[v.size() / 2 - 1] + v[v.size() / 2]);
+  };
   for (auto& kv : g_tuner.stats) {
     double best = 1e30; const TuneChoice* bc = nullptr;
-    for (auto& c : kv.second)
-      if (c.second.second > 0 && c.second.first / c.second.second < best) { best = c.second.first / c.second.second; bc = &c.first; }
+    for (auto& c : kv.second) {
+      const double sc = score(c.second);
+      if (sc < best) { best = sc; bc = &c.first; }
+    }
     if (bc) g_tuner.table[kv.first] = {bc->tile, bc->splitk, best};
   }
   if (n_keys) *n_keys = (int)g_tuner.stats.size();
@@ -1372,9 +1384,11 @@ int tune_dump(std::string* out) {
   for (auto& kv : g_tuner.stats) {
     const TuneKey& k = kv.first;
     for (auto& c : kv.second) {
-      if (!c.second.second) continue;
-      snprintf(buf, sizeof buf, "%d %d %d %d %d %d %d %d | %d %d %.2f %d\n", k.M, k.N, k.K, k.ksize, k.stride, k.up, k.mode,
-               k.splitk_req, c.first.tile, c.first.splitk, c.second.first / c.second.second, c.second.second);
+      if (c.second.empty()) continue;
+      std::vector<float> v = c.second;
+      std::sort(v.begin(), v.end());
+      snprintf(buf, sizeof buf, "%d %d %d %d %d %d %d %d | %d %d %.2f %.2f %d\n", k.M, k.N, k.K, k.ksize, k.stride, k.up, k.mode,
+               k.splitk_req, c.first.tile, c.first.splitk, (double)v[v.size() / 2], (double)v[0], (int)v.size());
       *out += buf;
     }
   }
@@ -1435,7 +1449,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
       IGemmParams q = p; q.splitk = splitk;
       const std::vector<TuneChoice> cands = tune_candidates(q, can_split);
       auto& st = g_tuner.stats[tkey];
-      if (st.empty()) for (auto& c : cands) st.push_back({c, {0.0, 0}});
+      if (st.empty()) for (auto& c : cands) st.push_back({c, {}});
       tcand = g_tuner.round % (int)cands.size();
       tile = cands[tcand].tile; splitk = cands[tcand].splitk;
       ev0 = g_tuner.ev(); ev1 = g_tuner.ev();

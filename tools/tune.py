@@ -24,8 +24,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'stable-diffusion_amd', 'tune_gfx950.txt'))
     ap.add_argument('--dump', default=None, help='also write the per-candidate timings here')
-    ap.add_argument('--rounds', type=int, default=64)
-    ap.add_argument('--reps', type=int, default=2)
+    ap.add_argument('--rounds', type=int, default=72)
+    ap.add_argument('--reps', type=int, default=3)
     ap.add_argument('--workloads', default='unet64,unet96,unet32,unet64b4,unet64b6,unet64b8,vaedec64,vaedec96,vaeenc512,clip')
     args = ap.parse_args()
     from stable_diffusion_amd import AutoencoderKLHIP, FrozenCLIPEmbedderHIP, UNetModelHIP, _lib
@@ -97,7 +97,7 @@ def main():
     if args.dump:
         buf = C.create_string_buffer(8 << 20)
         _lib.check(lib.sdmi_tune_dump(buf, len(buf)))
-        open(args.dump, 'w').write('# M N K ksize stride up mode splitk_req | tile splitk avg_us samples\n' + buf.value.decode())
+        open(args.dump, 'w').write('# M N K ksize stride up mode splitk_req | tile splitk median_us min_us samples\n' + buf.value.decode())
 
 
 if __name__ == '__main__':
