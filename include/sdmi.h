@@ -236,6 +236,10 @@ int sdmi_k_pointwise_nchw(const float* x, const float* w, const float* bias, flo
                           float in_scale, void* stream);
 int sdmi_k_softmax_rows(const float* S, void* P_f16, int rows, int cols, float scale, void* stream);
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst_f16, float* bdst, int N, int K, void* stream);
+/* Host post-processing of scripts/txt2img.py:313-324, on the device: img fp32 [B, C, H, W] (the
+ * decode_first_stage output) -> uint8 [B, H, W, C] = astype(uint8)(255 * clamp((img + 1) / 2, 0, 1)), bit-identical to
+ * the reference's torch / numpy ops. */
+int sdmi_image_to_uint8(const float* img_nchw, void* out_nhwc_u8, int B, int C, int H, int W, void* stream);
 /* fp16 range guard (debug; also SDMI_CHECK_RANGE=1 in the environment): after every launch that writes fp16 activations
  * (MFMA operands: GroupNorm / LayerNorm outputs, q / k / v^T, GEGLU, attention output, fp16 copies of the residual
  * stream) the buffer is scanned.  The reference has the same exposure under torch.autocast (scripts/txt2img.py:283);

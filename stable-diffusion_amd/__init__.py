@@ -18,5 +18,6 @@ from .samplers import PLMSSamplerHIP, DDIMSamplerHIP, DPMSolverSamplerHIP  # noq
 from .vae import AutoencoderKLHIP  # noqa: F401
 from .clip import FrozenCLIPEmbedderHIP  # noqa: F401
 from .ldm_shim import LatentDiffusionHIP, DiffusionWrapperHIP  # noqa: F401
+from . import debug, postprocess  # noqa: F401
 
 __all__ = ['UNetModelHIP', 'AutoencoderKLHIP', 'FrozenCLIPEmbedderHIP', 'PLMSSamplerHIP', 'DDIMSamplerHIP', 'DPMSolverSamplerHIP', 'LatentDiffusionHIP', 'DiffusionWrapperHIP']

@@ -106,6 +106,7 @@ _SIGS = {
     'sdmi_k_pack_conv_out': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_split3': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_geglu': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
+    'sdmi_image_to_uint8': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_range_check': (C.c_int, [C.c_int]),
     'sdmi_range_report': (C.c_int, [C.c_char_p, C.c_int]),
     'sdmi_tune_begin': (C.c_int, []),

@@ -315,6 +315,9 @@ int sdmi_k_pack_split3(const float* w, void* dst, int N, int K, void* stream) {
 int sdmi_k_pack_geglu(const float* w, const float* bias, void* wdst, float* bdst, int N, int K, void* stream) {
   return launch_pack_geglu(w, bias, (f16*)wdst, bdst, N, K, (hipStream_t)stream);
 }
+int sdmi_image_to_uint8(const float* img_nchw, void* out_nhwc_u8, int B, int C, int H, int W, void* stream) {
+  return launch_image_u8(img_nchw, (unsigned char*)out_nhwc_u8, B, C, H, W, (hipStream_t)stream);
+}
 int sdmi_range_check(int enable) { return range_check_set(enable); }
 int sdmi_range_report(char* buf, int buflen) {
   SDMI_CHECK(buf && buflen > 1, "null buffer");

@@ -249,5 +249,7 @@ struct SamplerStepParams {
   int64_t n = 0;                     // elements per output (B*4*H*W)
 };
 int launch_sampler_step(const SamplerStepParams& p, hipStream_t s);
+// decode output fp32 NCHW -> uint8 NHWC exactly as scripts/txt2img.py:313-324 does on the host (sampler.hip)
+int launch_image_u8(const float* img_nchw, unsigned char* out_nhwc, int B, int C, int H, int W, hipStream_t s);
 
 }  // namespace sdmi

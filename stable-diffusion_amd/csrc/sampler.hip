@@ -92,7 +92,33 @@ __global__ void __launch_bounds__(256) dpm_step_kernel(DpmStepParams p) {
   p.x_next[i] = xt;
 }
 
+// Host post-processing of scripts/txt2img.py:313-324 as one pass on the device: decode_first_stage output (fp32 NCHW,
+// nominally [-1, 1]) -> clamp((x + 1) / 2, 0, 1) -> NHWC -> 255 * x -> astype(uint8) (truncation, as numpy does).
+// Each step is the reference's own fp32 operation in its order (this file is compiled with -ffp-contract=off), so the
+// bytes equal the reference's exactly; 4x fewer bytes cross PCIe than with the fp32 image.
+__global__ void __launch_bounds__(256) image_u8_kernel(const float* img, unsigned char* out, int B, int C, int H, int W) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;        // (b, y, x)
+  const int64_t HW = (int64_t)H * W;
+  if (idx >= (int64_t)B * HW) return;
+  const int64_t b = idx / HW, pix = idx - b * HW;
+  for (int c = 0; c < C; ++c) {
+    float v = img[(b * C + c) * HW + pix];
+    v = (v + 1.0f) / 2.0f;                          // txt2img.py:314
+    v = fminf(fmaxf(v, 0.0f), 1.0f);                // torch.clamp(min=0, max=1) (a NaN stays NaN -> 0 below, as numpy's cast)
+    v = 255.0f * v;                                 // txt2img.py:323
+    out[idx * C + c] = (unsigned char)(int)v;       // astype(np.uint8): toward zero
+  }
+}
+
 }  // namespace
+
+int launch_image_u8(const float* img_nchw, unsigned char* out_nhwc, int B, int C, int H, int W, hipStream_t s) {
+  SDMI_CHECK(img_nchw && out_nhwc && B > 0 && C > 0 && H > 0 && W > 0, "image_u8: bad arguments");
+  const int64_t n = (int64_t)B * H * W;
+  hipLaunchKernelGGL(image_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img_nchw, out_nhwc, B, C, H, W);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
 
 int launch_dpm_step(const DpmStepParams& p, hipStream_t s) {
   SDMI_CHECK(p.n > 0 && p.eps_model && p.x && (p.m_out || p.x_next), "dpm_step: missing pointer");

@@ -191,3 +191,22 @@ def test_dpm_step_bit_exact(order, cfg):
                                                 _lib.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(m0, m0_ref) and torch.equal(xt, xt_ref)
+
+
+def test_image_postprocess_is_bit_identical_to_the_script(tmp_path):
+    """scripts/txt2img.py:314-326: clamp((x + 1) / 2) -> NHWC -> 255 * x -> astype(uint8) -> PNG, on the device in one pass."""
+    import numpy as np
+    from PIL import Image
+    from stable_diffusion_amd import postprocess
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(3, 3, 24, 40, generator=g) * 0.9
+    x[0, 0, 0, :8] = torch.tensor([-1.0, 1.0, -1.0000001, 0.9999999, 0.0, 1.5, -3.0, 0.99607843])     # range ends, 254/255
+    ref = torch.clamp((x + 1.0) / 2.0, min=0.0, max=1.0).permute(0, 2, 3, 1).numpy()
+    ref = (255. * ref).astype(np.uint8)
+    out = postprocess.to_uint8_images(x.cuda())
+    assert out.dtype == torch.uint8 and tuple(out.shape) == (3, 24, 40, 3)
+    assert np.array_equal(out.cpu().numpy(), ref)
+    path = postprocess.save_png(out[1], str(tmp_path / 'a.png'))
+    assert np.array_equal(np.array(Image.open(path)), ref[1])
+    with pytest.raises(RuntimeError, match='no CPU'):
+        postprocess.to_uint8_images(x)
