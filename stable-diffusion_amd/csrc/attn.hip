@@ -22,6 +22,21 @@ namespace sdmi {
 namespace {
 
 constexpr int KVT = 64;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int N>
+__device__ __forceinline__ void wait_dma() {          // counted s_waitcnt vmcnt(N): the immediate must be a literal
+  static_assert(N >= 0 && N <= 44, "add the literal");
+  switch (N) {
+#define SDMI_VM(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break
+    SDMI_VM(0); SDMI_VM(1); SDMI_VM(2); SDMI_VM(3); SDMI_VM(4); SDMI_VM(5); SDMI_VM(6); SDMI_VM(7); SDMI_VM(8); SDMI_VM(9);
+    SDMI_VM(10); SDMI_VM(11); SDMI_VM(12); SDMI_VM(13); SDMI_VM(14); SDMI_VM(15); SDMI_VM(16); SDMI_VM(17); SDMI_VM(18);
+    SDMI_VM(19); SDMI_VM(20); SDMI_VM(21); SDMI_VM(22); SDMI_VM(23); SDMI_VM(24); SDMI_VM(25); SDMI_VM(26); SDMI_VM(27);
+    SDMI_VM(28); SDMI_VM(29); SDMI_VM(30); SDMI_VM(31); SDMI_VM(32); SDMI_VM(33); SDMI_VM(34); SDMI_VM(35); SDMI_VM(36);
+    SDMI_VM(37); SDMI_VM(38); SDMI_VM(39); SDMI_VM(40); SDMI_VM(41); SDMI_VM(42); SDMI_VM(43); SDMI_VM(44);
+#undef SDMI_VM
+  }
+}
 
 template <int D, int NW, bool CAUSAL>
 __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
@@ -227,6 +242,213 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
   }
 }
 
+// ---- LDS-DMA variant ---------------------------------------------------------------------------------------------------
+// Same algorithm as attn_kernel, re-cut around what actually bounds it: the per-score VALU work (v_exp_f32 is quarter rate:
+// 32 scores x 16 cycles per 64-key tile and wave exceed the 14 MFMAs x 32 cycles of d = 40), not the matrix cores.
+//   * the K / V^T tiles arrive by LDS-DMA into an NS-deep ring: no VALU / VGPRs spent on staging, NS - 1 tiles in flight;
+//   * the keys of a tile sit in LDS in a permuted order (bits 2 and 3 of the row swapped), which makes the eight keys a lane
+//     owns in a P^T fragment CONTIGUOUS in the V^T row: one ds_read_b128 per fragment instead of two b64 + a repack;
+//   * scale / subtract and the row sum run as packed fp32 (v_pk_fma_f32, v_pk_add_f32).  The register-staged
+// loop above spends ~0.4 us of MFMA + softmax per 64-key tile and then waits for the NEXT tile's global loads, which were
+// issued only one tile earlier: every iteration exposes the L2 latency (wait_any 44 % of the wave cycles, MFMA busy 26 %,
+// profiles/pmc_sq_by_kernel_r02.txt).  Here NS - 1 tiles are in flight, retired by a counted vmcnt.
+//   LDS image of a stage (rows of 128 B, 16-byte chunks XOR-swizzled with (row >> 1) & 7 on the DMA *source* side, like
+//   the GEMM tiles): K as ceil(D / 64) sub-tiles [64 keys][64 halves of d]; V^T as DVT sub-tiles [32 d-rows][64 keys].
+//   Rows / columns past the tensors are out-of-range buffer offsets (zeros) or finite neighbouring data that the zero pad
+//   of Q, the score mask and the zero columns of V^T (nkv .. nkv_pad) neutralise.
+template <int D, int NW, int NS, bool CAUSAL>
+__global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int DKS = (D + 15) / 16;   // k-steps of 16 over the head dim (QK^T)
+  constexpr int DVT = (D + 31) / 32;   // 32-row tiles over the head dim (PV)
+  constexpr int NCH = (D + 63) / 64;   // 64-half chunks of a K row
+  constexpr int KROWS = NCH * 64, VROWS = DVT * 32;
+  constexpr int STAGE = (KROWS + VROWS) * 128;
+  constexpr int PK = NCH * 8, PV = DVT * 4, PT = PK + PV;          // DMA pieces (8 rows x 128 B each) per tile
+  constexpr int PPW = (PT + NW - 1) / NW;                          // per wave (the surplus re-issues the last piece)
+  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS budget");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lg = lane >> 5;
+  const int bh = blockIdx.y;
+  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  const f16* Qg = p.q + (size_t)bh * p.nq * D;
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rsrc_k =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (size_t)bh * p.nkv * D), 0, p.nkv * D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_v =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + (size_t)bh * D * p.nkv_pad), 0, D * p.nkv_pad * 2, 0x00020000);
+
+  // Q^T fragments (MFMA B operand): lane (q = l31, g = lg) holds Q[q][16*ks + 8*g .. +8]; zero beyond D / nq
+  f16x8 qf[DKS];
+#pragma unroll
+  for (int ks = 0; ks < DKS; ++ks) {
+    const int dcol = ks * 16 + lg * 8;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q0 + l31 < p.nq && dcol < D) v = *(const f16x8*)(Qg + (size_t)(q0 + l31) * D + dcol);
+    qf[ks] = v;
+  }
+
+  // this wave's DMA pieces: q = wave + j * NW (clamped): per-lane byte offset at tile 0, per-tile increment, LDS row
+  int pv_off[PPW], pv_step[PPW], pv_row[PPW];
+  bool pv_isk[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = min(wave + j * NW, PT - 1);
+    const int r8 = lane >> 3, cp = lane & 7;
+    if (q < PK) {
+      const int c = q >> 3, row = (q & 7) * 8 + r8;               // LDS row; it holds key perm(row) of the tile
+      const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+      const int gch = cp ^ ((row >> 1) & 7);
+      pv_off[j] = key * (D * 2) + c * 128 + gch * 16;
+      pv_step[j] = KVT * D * 2;
+      pv_row[j] = c * 64 + (q & 7) * 8;
+      pv_isk[j] = true;
+    } else {
+      const int qv = q - PK, dt = qv >> 2, row = (qv & 3) * 8 + r8;       // row inside the 32-row sub-tile
+      const int d = dt * 32 + row;
+      const int gch = cp ^ ((row >> 1) & 7);
+      pv_off[j] = d < D ? d * (p.nkv_pad * 2) + gch * 16 : OOB;
+      pv_step[j] = d < D ? KVT * 2 : 0;
+      pv_row[j] = KROWS + dt * 32 + (qv & 3) * 8;
+      pv_isk[j] = false;
+    }
+  }
+  auto issue_tile = [&](int stage) {      // advances the per-lane offsets: call once per tile, in order
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      auto dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE + pv_row[j] * 128);
+      if (pv_isk[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dst, 16, pv_off[j], 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dst, 16, pv_off[j], 0, 0, 0);
+      // (offsets past the tensor end stay out of range: they only grow; the OOB marker has a zero step)
+      pv_off[j] += pv_step[j];
+    }
+  };
+
+  f32x16 o[DVT];
+#pragma unroll
+  for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  const float sc = p.scale * 1.4426950408889634f;   // scores are compared / exponentiated in log2 units
+
+  const int nt = (p.nkv + KVT - 1) / KVT;
+#pragma unroll
+  for (int s2 = 0; s2 < NS - 1; ++s2) issue_tile(s2);          // (tiles past nt read out of range: zeros, never consumed)
+  wait_dma<PPW*(NS - 2)>();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  const int ksw = (l31 >> 1) & 7;
+  int cur = 0, nxt = NS - 1;
+  for (int t = 0; t < nt; ++t) {
+    issue_tile(nxt);
+    const unsigned char* Ks = smem + cur * STAGE;
+    const unsigned char* Vs = Ks + KROWS * 128;
+
+    // ---- S^T = K Q^T (two 32-key blocks) ----
+    f32x16 s[KVT / 32];
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kvb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < DKS; ++ks) {
+        const unsigned char* kp = Ks + ((ks >> 2) * 64 + kvb * 32 + l31) * 128 + ((((ks & 3) * 2 + lg) ^ ksw) << 4);
+        const f16x8 a = *(const f16x8*)kp;
+        s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
+      }
+    }
+    const int kv0 = t * KVT;
+    if (CAUSAL || kv0 + KVT > p.nkv) {
+      asm volatile("; masked tile" ::: "memory");
+      const int qlim = CAUSAL ? (q0 + l31) : 0x7fffffff;
+#pragma unroll
+      for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + kvb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * lg + 16 * (r >> 3);   // (permuted rows)
+          if (kv >= p.nkv || kv > qlim) s[kvb][r] = -1e30f;
+        }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx * sc);
+    if (__any(m_new > m_run)) {
+      asm volatile("; rescale" ::: "memory");
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    f32x2 psum2 = {0.f, 0.f};
+    const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {s[kvb][r], s[kvb][r + 1]};
+        const f32x2 e = __builtin_elementwise_fma(sv, sc2, nm2);
+        const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        s[kvb][r] = pv[0];
+        s[kvb][r + 1] = pv[1];
+        psum2 += pv;
+      }
+    l_run += psum2[0] + psum2[1];
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb) {
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        f16x8 pf;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[e] = (f16)s[kvb][8 * s2 + e];
+        const int ch = 4 * kvb + 2 * s2;        // + lg: the 16-byte chunk with this lane's eight keys (see the row permutation)
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+          const f16x8 a = *(const f16x8*)(Vs + (dt * 32 + l31) * 128 + (((ch + lg) ^ ksw) << 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, o[dt], 0, 0, 0);
+        }
+      }
+    }
+    wait_dma<PPW*(NS - 2)>();                            // this wave's pieces of tile t + 1 have landed
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; and tile t is fully read
+    cur = (cur + 1 == NS) ? 0 : cur + 1;
+    nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+  }
+  wait_dma<0>();
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.nq) {
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    f16* orow = p.out + ((size_t)b * p.nq + q) * ((size_t)p.heads * D) + (size_t)head * D;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dd = dt * 32 + 8 * r4 + 4 * lg;
+        if (dd < D) {
+          f16x4 v = {(f16)(o[dt][r4 * 4 + 0] * inv), (f16)(o[dt][r4 * 4 + 1] * inv), (f16)(o[dt][r4 * 4 + 2] * inv),
+                     (f16)(o[dt][r4 * 4 + 3] * inv)};
+          *(f16x4*)(orow + dd) = v;
+        }
+      }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 template <int D>
 int launch_d(const AttnParams& p, hipStream_t stream) {
   // Long sequences (> 1024 queries): 8 waves share each K/V tile.  Short ones (the 32x32 / 16x16 / 8x8 levels) are
@@ -242,7 +464,13 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
   dim3 grid(cdiv(p.nq, 32 * nw), p.BH);
   static const std::string pname = std::string("attn_d") + std::to_string(D);
   ProfScope ps(pname.c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
-  if (p.causal) {          // the text encoder's 77-token self-attention: one configuration is enough
+  static const int use_v1 = getenv("SDMI_ATTN_V1") ? atoi(getenv("SDMI_ATTN_V1")) : 0;     // A/B: the register-staged kernel
+  constexpr int DNS = (D > 128) ? 3 : 4;                        // LDS-DMA ring depth (D = 160: 3 x 44 KB)
+  if (!use_v1 && !p.causal && (p.nkv * D) % 8 == 0) {
+    if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
+    else if (nw == 4) hipLaunchKernelGGL((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);
+  } else if (p.causal) {          // the text encoder's 77-token self-attention: one configuration is enough
     if constexpr (D == 32 || D == 64 || D == 128) hipLaunchKernelGGL((attn_kernel<D, 2, true>), dim3(cdiv(p.nq, 64), p.BH), dim3(128), 0, stream, p);
     else return fail("causal attention is instantiated for head dims 32 / 64 / 128");
   } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<D, 8, false>), grid, dim3(512), 0, stream, p);
