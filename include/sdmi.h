@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 6
+#define SDMI_ABI_VERSION 7
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -180,7 +180,7 @@ typedef struct sdmi_igemm_desc {
   void* seg_dst[3]; int32_t seg_kind[3];
   int32_t heads, dh, ntok, ntok_pad, segC;
   int32_t splitk;                       /* 1 none, 0 auto, >1 forced (plain mode; needs splitk_ws) */
-  float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs [splitk][M][N] */
+  float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs (layout: see splitk_cnt) */
   int32_t tile;                         /* -1 auto (tuning table); BMxBN/waves/LDS-DMA stages: 0 128x128/4/2, 1 128x64/4/2,
                                            2 64x64/4/2, 3 256x128/8/2, 4 128x64/4/3, 5 64x64/4/3, 6 256x128/8/3, 7 128x128/4/3,
                                            8 64x128/4/3, 9 128x128/8/3, 10 64x64/4/4, 11 128x256/8/2, 12 64x256/4/3, 13 256x64/4/3;
@@ -196,6 +196,11 @@ typedef struct sdmi_igemm_desc {
    * sumsq frac * 2^40}; zero them first);
    * the output is channels [gn_cbase, gn_cbase + N) of that GroupNorm's input, gn_cpg channels per group */
   int32_t gn_n; void* gn_acc[2]; int32_t gn_cpg[2]; int32_t gn_cbase[2];
+  /* optional: one int per output tile, zero before the first launch (the kernel leaves them zero).  With it the split-K
+   * reduction happens inside the GEMM (the last block of a tile to arrive sums the splits in index order and runs the
+   * epilogue; no reduce launch) and splitk_ws holds splitk * round_up(M, BM) * round_up(N, BN) floats in register order;
+   * without it: slabs [splitk][M][N] and a separate reduce kernel */
+  int32_t* splitk_cnt; int32_t splitk_cnt_ints;
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */

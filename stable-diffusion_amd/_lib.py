@@ -41,7 +41,8 @@ class IGemmDesc(C.Structure):
                 ('heads', C.c_int32), ('dh', C.c_int32), ('ntok', C.c_int32), ('ntok_pad', C.c_int32),
                 ('segC', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', c_ptr), ('splitk_ws_floats', C.c_int64),
                 ('tile', C.c_int32), ('dma', C.c_int32), ('asym_pad', C.c_int32),
-                ('gn_n', C.c_int32), ('gn_acc', c_ptr * 2), ('gn_cpg', C.c_int32 * 2), ('gn_cbase', C.c_int32 * 2)]
+                ('gn_n', C.c_int32), ('gn_acc', c_ptr * 2), ('gn_cpg', C.c_int32 * 2), ('gn_cbase', C.c_int32 * 2),
+                ('splitk_cnt', c_ptr), ('splitk_cnt_ints', C.c_int32)]
 
 
 _SIGS = {
@@ -137,7 +138,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 6:
+        if lib.sdmi_abi_version() != 7:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

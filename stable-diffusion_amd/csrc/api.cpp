@@ -237,6 +237,7 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   for (int i = 0; i < 3; ++i) { p.seg_dst[i] = (f16*)d->seg_dst[i]; p.seg_kind[i] = d->seg_kind[i]; }
   p.heads = d->heads; p.dh = d->dh; p.ntok = d->ntok; p.ntok_pad = d->ntok_pad; p.segC = d->segC;
   p.splitk = d->splitk; p.splitk_ws = d->splitk_ws; p.splitk_ws_floats = d->splitk_ws_floats;
+  p.splitk_cnt = d->splitk_cnt; p.splitk_cnt_ints = d->splitk_cnt_ints;
   p.gn_n = d->gn_n;
   for (int i = 0; i < 2; ++i) { p.gn_acc[i] = (long long*)d->gn_acc[i]; p.gn_cpg[i] = d->gn_cpg[i]; p.gn_cbase[i] = d->gn_cbase[i]; }
   if (zero_page(&p.zero_page)) return -1;

@@ -23,6 +23,8 @@ namespace {
 
 constexpr int KVT = 64;
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 template <int N>
 __device__ __forceinline__ void wait_dma() {          // counted s_waitcnt vmcnt(N): the immediate must be a literal
@@ -242,6 +244,34 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
   }
 }
 
+// Workgroups are dealt to the 8 XCDs round-robin by linear id, and each XCD has its own 4 MB L2.  With the natural
+// (q tile, head) numbering every XCD sees every head's K / V^T (SD-v1 64x64 level: 16 heads x 656 KB = 10.5 MB, more than
+// one L2), and the tiles stream from the fabric instead.  Renumber so that one XCD owns whole heads.
+__device__ __forceinline__ void head_of_block(int& bh, int& qt) {
+  const unsigned nqt = gridDim.x, total = gridDim.x * gridDim.y;
+  unsigned lin = blockIdx.x + nqt * blockIdx.y;
+  if ((total & 7) == 0) lin = (lin & 7) * (total >> 3) + (lin >> 3);
+  bh = (int)(lin / nqt);
+  qt = (int)(lin - (unsigned)bh * nqt);
+}
+
+// max / sum over the two 32-lane halves of the wave, in every lane.  v_permlane32_swap is a VALU instruction; the
+// ds_bpermute that __shfl_xor(x, 32) turns into queues behind the wave's outstanding LDS fragment reads (and its
+// lgkmcnt(0) waits for them).  Inline asm: this compiler returns the first result twice from the builtin.
+__device__ __forceinline__ void swap_halves(float& a, float& b) {      // a.hi <-> b.lo
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float max_across_halves(float x) {
+  float a = x, b = x;
+  swap_halves(a, b);
+  return fmaxf(a, b);
+}
+__device__ __forceinline__ float sum_across_halves(float x) {
+  float a = x, b = x;
+  swap_halves(a, b);
+  return a + b;
+}
+
 // ---- LDS-DMA variant ---------------------------------------------------------------------------------------------------
 // Same algorithm as attn_kernel, re-cut around what actually bounds it: the per-score VALU work (v_exp_f32 is quarter rate:
 // 32 scores x 16 cycles per 64-key tile and wave exceed the 14 MFMAs x 32 cycles of d = 40), not the matrix cores.
@@ -256,7 +286,10 @@ __global__ void __launch_bounds__(NW * 64) attn_kernel(const AttnParams p) {
 //   the GEMM tiles): K as ceil(D / 64) sub-tiles [64 keys][64 halves of d]; V^T as DVT sub-tiles [32 d-rows][64 keys].
 //   Rows / columns past the tensors are out-of-range buffer offsets (zeros) or finite neighbouring data that the zero pad
 //   of Q, the score mask and the zero columns of V^T (nkv .. nkv_pad) neutralise.
-template <int D, int NW, int NS, bool CAUSAL>
+// ABL != 0: timing-only ablations (wrong results) that price one ingredient of the loop at a time (tools/attn_ablate.py):
+//   1 no per-tile wait + barrier, 2 no DMA issue, 3 exp2 replaced by a move, 4 no PV MFMAs, 5 no QK^T MFMAs,
+//   6 K / V^T fragments read from LDS once (first tile) only
+template <int D, int NW, int NS, bool CAUSAL, int ABL = 0>
 __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DKS = (D + 15) / 16;   // k-steps of 16 over the head dim (QK^T)
@@ -273,8 +306,9 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lg = lane >> 5;
-  const int bh = blockIdx.y;
-  const int q0 = blockIdx.x * (32 * NW) + wave * 32;
+  int bh, qt;
+  head_of_block(bh, qt);
+  const int q0 = qt * (32 * NW) + wave * 32;
   const f16* Qg = p.q + (size_t)bh * p.nq * D;
   constexpr int OOB = (int)0x80000000;
   const __amdgpu_buffer_rsrc_t rsrc_k =
@@ -344,8 +378,8 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   const int ksw = (l31 >> 1) & 7;
   int cur = 0, nxt = NS - 1;
   for (int t = 0; t < nt; ++t) {
-    issue_tile(nxt);
-    const unsigned char* Ks = smem + cur * STAGE;
+    if (ABL != 2) issue_tile(nxt);
+    const unsigned char* Ks = smem + (ABL == 6 ? 0 : cur) * STAGE;
     const unsigned char* Vs = Ks + KROWS * 128;
 
     // ---- S^T = K Q^T (two 32-key blocks) ----
@@ -358,6 +392,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
       for (int ks = 0; ks < DKS; ++ks) {
         const unsigned char* kp = Ks + ((ks >> 2) * 64 + kvb * 32 + l31) * 128 + ((((ks & 3) * 2 + lg) ^ ksw) << 4);
         const f16x8 a = *(const f16x8*)kp;
+        if (ABL == 5) { s[kvb][ks] += (float)a[0]; continue; }
         s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
       }
     }
@@ -378,7 +413,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
     for (int kvb = 0; kvb < KVT / 32; ++kvb)
 #pragma unroll
       for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvb][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    mx = max_across_halves(mx);
     const float m_new = fmaxf(m_run, mx * sc);
     if (__any(m_new > m_run)) {
       asm volatile("; rescale" ::: "memory");
@@ -398,7 +433,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
       for (int r = 0; r < 16; r += 2) {
         const f32x2 sv = {s[kvb][r], s[kvb][r + 1]};
         const f32x2 e = __builtin_elementwise_fma(sv, sc2, nm2);
-        const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        const f32x2 pv = {ABL == 3 ? e[0] : __builtin_amdgcn_exp2f(e[0]), ABL == 3 ? e[1] : __builtin_amdgcn_exp2f(e[1])};
         s[kvb][r] = pv[0];
         s[kvb][r + 1] = pv[1];
         psum2 += pv;
@@ -417,18 +452,21 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #pragma unroll
         for (int dt = 0; dt < DVT; ++dt) {
           const f16x8 a = *(const f16x8*)(Vs + (dt * 32 + l31) * 128 + (((ch + lg) ^ ksw) << 4));
+          if (ABL == 4) { o[dt][kvb * 2 + s2] += (float)a[0] * (float)pf[0]; continue; }
           o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf, o[dt], 0, 0, 0);
         }
       }
     }
-    wait_dma<PPW*(NS - 2)>();                            // this wave's pieces of tile t + 1 have landed
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; and tile t is fully read
+    if (ABL != 1) {
+      wait_dma<PPW*(NS - 2)>();                            // this wave's pieces of tile t + 1 have landed
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; and tile t is fully read
+    }
     cur = (cur + 1 == NS) ? 0 : cur + 1;
     nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
   wait_dma<0>();
 
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float l_tot = sum_across_halves(l_run);
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
   if (q < p.nq) {
@@ -458,16 +496,31 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
     const int slices = cdiv(p.nq, 32);
     // (same-box A/B, profiles/ab_*_r01.txt: 4 waves beat 8 up to 1024 queries -- more, smaller workgroups)
     nw = (slices >= 8 && p.nq > 1024) ? 8 : (slices >= 4 ? 4 : 2);
-    static const int env_small = getenv("SDMI_ATTN_NW_LE1K") ? atoi(getenv("SDMI_ATTN_NW_LE1K")) : 0;   // A/B knob
+    static const int env_small = getenv("SDMI_ATTN_NW_LE1K") ? atoi(getenv("SDMI_ATTN_NW_LE1K")) : 0;   // A/B knobs
+    static const int env_big = getenv("SDMI_ATTN_NW_GT1K") ? atoi(getenv("SDMI_ATTN_NW_GT1K")) : 0;
     if (env_small > 0 && p.nq <= 1024) nw = env_small;
+    if (env_big > 0 && p.nq > 1024) nw = env_big;
   }
   dim3 grid(cdiv(p.nq, 32 * nw), p.BH);
-  static const std::string pname = std::string("attn_d") + std::to_string(D);
-  ProfScope ps(pname.c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
+  static const std::string pname_long = std::string("attn_d") + std::to_string(D) + "_self";
+  static const std::string pname_short = std::string("attn_d") + std::to_string(D) + "_ctx";
+  ProfScope ps((p.nkv >= 256 ? pname_long : pname_short).c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
   static const int use_v1 = getenv("SDMI_ATTN_V1") ? atoi(getenv("SDMI_ATTN_V1")) : 0;     // A/B: the register-staged kernel
   constexpr int DNS = (D > 128) ? 3 : 4;                        // LDS-DMA ring depth (D = 160: 3 x 44 KB)
   if (!use_v1 && !p.causal && (p.nkv * D) % 8 == 0) {
-    if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
+    static const int abl = getenv("SDMI_ATTN_ABL") ? atoi(getenv("SDMI_ATTN_ABL")) : 0;     // timing-only, see the kernel
+    if (D == 40 && nw == 8 && abl) {
+      if constexpr (D == 40) {
+        switch (abl) {
+          case 1: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 1>), grid, dim3(512), 0, stream, p); break;
+          case 2: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 2>), grid, dim3(512), 0, stream, p); break;
+          case 3: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 3>), grid, dim3(512), 0, stream, p); break;
+          case 4: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 4>), grid, dim3(512), 0, stream, p); break;
+          case 5: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 5>), grid, dim3(512), 0, stream, p); break;
+          default: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 6>), grid, dim3(512), 0, stream, p); break;
+        }
+      }
+    } else if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
     else if (nw == 4) hipLaunchKernelGGL((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);
   } else if (p.causal) {          // the text encoder's 77-token self-attention: one configuration is enough

@@ -87,6 +87,12 @@ struct IGemmParams {
   // ([split][M][N]); a second kernel sums the slabs in a fixed order and applies the epilogue (deterministic).
   int splitk = 1;                                      // 1 none, 0 auto, >1 forced
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
+  // fused reduction (default when splitk_cnt is given): every split stores its accumulators in register order, takes a
+  // ticket from the tile's counter, and the LAST block to arrive sums the splits in index order and runs the normal
+  // epilogue -- no reduce kernel.  Counters: one int per output tile, zero before the first launch (the last block resets
+  // its counter).  Slabs then need splitk * round_up(M, BM) * round_up(N, BN) floats.
+  int* splitk_cnt = nullptr; int splitk_cnt_ints = 0;
+  int splitk_fused = 0;                                // set by the launcher
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
   // optional (plain mode): GroupNorm(32) statistics of the finished output for up to two consuming GroupNorms -- the
   // output's channels are channels [gn_cbase, gn_cbase + N) of that GroupNorm's (possibly concatenated) input with

@@ -32,6 +32,7 @@
 #include "prof.h"
 
 namespace sdmi {
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
 
@@ -114,8 +115,59 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
   // (independent), column terms are hoisted, and no per-element bounds checks split the stores into dependent
   // load -> wait -> store chains (those chains were ~70 % of the short-K kernels' time, profiles/ablate2_r01.txt).
   const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+  if (p.splitk > 1 && p.splitk_fused) {
+    // ---- fused split-K reduction: accumulators to this split's slab in register order (16 bytes per lane, a wave writes
+    // 1 KB runs), ticket; all but the last block of the tile are done.  The last one re-reads every split's slab IN INDEX
+    // ORDER (its own included: the sum does not depend on which block came last) and falls through to the ordinary
+    // epilogue.  The blocks of a tile run on different XCDs, whose L2s are not coherent with each other: the slab stores
+    // and loads carry the agent-scope bit (sc1: performed at the memory side), which orders them against the ticket
+    // with plain s_waitcnt -- an agent-scope release / acquire FENCE instead writes back / invalidates the whole L2
+    // per wave and cost ~60 us per GEMM (profiles/splitk_fused_r02.txt).
+    constexpr int SC1 = 16;                                // buffer cache-policy bit: agent scope
+    const int tile_lin = tile_m * ((p.N + BN - 1) / BN) + tile_n;
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.splitk_ws + (size_t)tile_lin * p.splitk * (BM * BN)), 0, p.splitk * (BM * BN) * 4, 0x00020000);
+    const int my_off = (split * (BM * BN) + tid * 4) * 4;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws, my_off + ((i * TN + j) * 4 + r4) * (NT * 16), 0, SC1);
+        }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's slab stores are performed ...
+    __syncthreads();                                       // ... every wave's (and the LDS is free: all are out of the k-loop)
+    if (tid == 0) *(volatile int*)smem = __hip_atomic_fetch_add(p.splitk_cnt + tile_lin, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    const int ticket = *(volatile int*)smem;
+    if (ticket != p.splitk - 1) return;
+    if (tid == 0) __hip_atomic_store(p.splitk_cnt + tile_lin, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < p.splitk; ++s) {
+      const int off = (s * (BM * BN) + tid * 4) * 4;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, off + ((i * TN + j) * 4 + r4) * (NT * 16), 0, SC1));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
+          }
+    }
+    __syncthreads();                       // smem[0] is reused below
+  }
+  const bool unfused_split = p.splitk > 1 && !p.splitk_fused;
   if (p.mode == EPI_PLAIN) {
-    const bool atomic = p.splitk > 1;      // split-K: raw partial sums go to this split's slab
+    const bool atomic = unfused_split;     // unfused split-K: raw partial sums go to this split's slab
     float* slab = atomic ? (p.splitk_ws + (size_t)split * p.M * p.N) : nullptr;
     const int b_first = m0 / HWout;
     const bool one_batch = ((m0 + BM - 1) / HWout == b_first);
@@ -301,7 +353,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
       }
     }
   } else {  // EPI_HEADS
-    if (p.splitk > 1) {   // split-K: raw partial tile to this split's slab; splitk_reduce_heads_kernel scatters the sum
+    if (unfused_split) {   // raw partial tile to this split's slab; splitk_reduce_heads_kernel scatters the sum
       float* slab = p.splitk_ws + (size_t)split * p.M * p.N;
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -1032,6 +1084,19 @@ static unsigned long long div_magic(int d) {      // ceil(2^40 / d), see fast_di
   return (one + (unsigned long long)d - 1) / (unsigned long long)d;
 }
 
+// split-K slabs a (tile, split) choice needs, in floats: register-order slabs of whole tiles when the reduction is fused
+// into the GEMM (see igemm_epilogue), [split][M][N] for the separate reduce kernel
+static bool splitk_fusable(const IGemmParams& p, int bm, int bn) {
+  // default off: same-box A/B (profiles/splitk_fused_r02.txt) has the separate reduce kernel ahead, 3.23 vs 3.16 images/s
+  static const int env_fused = env_int("SDMI_SPLITK_FUSED", 0);
+  return env_fused && p.splitk_cnt && (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn) <= p.splitk_cnt_ints;
+}
+static int64_t splitk_ws_need(const IGemmParams& p, int bm, int bn, int nsplit) {
+  if (nsplit <= 1) return 0;
+  if (splitk_fusable(p, bm, bn)) return (int64_t)nsplit * cdiv(p.M, bm) * bm * cdiv(p.N, bn) * bn;
+  return (int64_t)nsplit * p.M * p.N;
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
@@ -1040,6 +1105,8 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int nsplit = cdiv(nkt, kt_per_split);
   IGemmParams q = p;
   q.splitk = nsplit;
+  q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
+  SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
@@ -1071,7 +1138,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
 #undef SDMI_LAUNCH_KIND
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
-  if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);     // (+ the LayerNorm launch when q.ln_out)
+  if (nsplit > 1 && !q.splitk_fused) return launch_splitk_reduce(q, nsplit, stream);     // (+ the LayerNorm launch when q.ln_out)
   if (q.ln_out) return launch_layernorm(q.out_f32, q.ln_gamma, q.ln_beta, q.ln_out, q.M, q.N, q.ln_eps, stream);
   return 0;
 }
@@ -1124,6 +1191,8 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   const int nsplit = cdiv(nch, chunks_per_split);
   IGemmParams q = p;
   q.splitk = nsplit;
+  q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
+  SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   q.magic_w2 = div_magic(p.Wout + 2);
@@ -1154,7 +1223,7 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   hipLaunchKernelGGL((conv3halo_kernel<BM, BN, WARPS_M, WARPS_N, NS>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
-  if (nsplit > 1) return launch_splitk_reduce(q, nsplit, stream);
+  if (nsplit > 1 && !q.splitk_fused) return launch_splitk_reduce(q, nsplit, stream);
   if (q.ln_out) return launch_layernorm(q.out_f32, q.ln_gamma, q.ln_beta, q.ln_out, q.M, q.N, q.ln_eps, stream);
   return 0;
 }
@@ -1308,7 +1377,7 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
         if (nkt / sk < 4) break;                                       // >= 4 k-tiles per split
         if (tile_is_halo(t) && (nkt / 9) % sk != 0) continue;          // halo tiles split at 64-channel chunk granularity
         if (blocks * (sk / 2 + 1) > 1536) break;                       // already plenty of blocks one step earlier
-        if ((int64_t)sk * p.M * p.N > p.splitk_ws_floats) break;
+        if (splitk_ws_need(p, c.bm, c.bn, sk) > p.splitk_ws_floats) break;
       }
       if (blocks * sk < 48 && sk < 16 && nkt / (sk * 2) >= 4 && can_split && p.splitk == 0) continue;   // hopelessly few blocks
       out.push_back({t, p.splitk > 1 ? p.splitk : sk, 0.0});
@@ -1455,7 +1524,9 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
       ev0 = g_tuner.ev(); ev1 = g_tuner.ev();
     } else {
       auto it = g_tuner.table.find(tkey);
-      if (it != g_tuner.table.end() && (it->second.splitk == 1 || (can_split && (int64_t)it->second.splitk * p.M * p.N <= p.splitk_ws_floats)) &&
+      if (it != g_tuner.table.end() &&
+          (it->second.splitk == 1 || (can_split && splitk_ws_need(p, kTiles[it->second.tile].bm, kTiles[it->second.tile].bn,
+                                                                  it->second.splitk) <= p.splitk_ws_floats)) &&
           (p.mode != EPI_GEGLU || tile_tn_even(it->second.tile)) &&
           (!tile_is_halo(it->second.tile) || halo_supported(p, kTiles[it->second.tile].bm))) {
         tile = it->second.tile; splitk = it->second.splitk;
@@ -1476,13 +1547,13 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
       const long blocks = (long)cdiv(p.M, kTiles[tile].bm) * cdiv(p.N, kTiles[tile].bn);
       const long want = (kTiles[tile].wm * kTiles[tile].wn == 8) ? 160 : 512;
       while (blocks * splitk < want && nkt / (splitk * 2) >= 8 && splitk < 16 &&
-             (int64_t)(splitk * 2) * p.M * p.N <= p.splitk_ws_floats)
+             splitk_ws_need(p, kTiles[tile].bm, kTiles[tile].bn, splitk * 2) <= p.splitk_ws_floats)
         splitk *= 2;
     }
   }
   if (splitk > 1) {
     SDMI_CHECK(can_split, "split-K needs plain or head-scatter mode, a slab workspace and N / ldo / ldr multiples of 4");
-    SDMI_CHECK((int64_t)splitk * p.M * p.N <= p.splitk_ws_floats, "split-K workspace too small");
+    SDMI_CHECK(splitk_ws_need(p, kTiles[tile].bm, kTiles[tile].bn, splitk) <= p.splitk_ws_floats, "split-K workspace too small");
   }
   if (ev0) SDMI_HIP_OK(hipEventRecord(ev0, stream));
   const int rc = launch_tile(tile, p, dma, splitk, stream);

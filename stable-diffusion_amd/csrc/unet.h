@@ -46,6 +46,8 @@ struct FwdBase {
   long long* gn_acc = nullptr;   // GN_MAX_CALLS regions of gn_acc_words(B) int64, zeroed once per forward
   int gn_calls = 0;
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
+  int* splitk_cnt = nullptr;                          // one int per output tile of a split-K GEMM (igemm.hip)
+  static constexpr int SPLITK_CNT_INTS = 8192;
   int rc = 0;
   GnPlan* plan = nullptr;         // null: GroupNorm statistics always by the statistics kernel (first stage, text encoder)
   int n_acts = 0;
@@ -81,10 +83,13 @@ struct FwdBase {
   int begin_pass(int64_t splitk_floats, bool with_gn = true) {
     gn_calls = 0;
     gn_acc = nullptr;
-    if (with_gn) {
-      gn_acc = P<long long>((size_t)GN_MAX_CALLS * gn_acc_words(B));
-      if (!dry) SDMI_HIP_OK(hipMemsetAsync(gn_acc, 0, (size_t)GN_MAX_CALLS * gn_acc_words(B) * sizeof(long long), s));
-    }
+    // the split-K tile counters sit behind the accumulators so that one memset clears both (the counters reset themselves;
+    // clearing them per pass only guards against a pass that was aborted mid-kernel)
+    const size_t acc_words = with_gn ? (size_t)GN_MAX_CALLS * gn_acc_words(B) : 0;
+    long long* blk = P<long long>(acc_words + SPLITK_CNT_INTS / 2);
+    gn_acc = with_gn ? blk : nullptr;
+    splitk_cnt = (int*)(blk + acc_words);
+    if (!dry) SDMI_HIP_OK(hipMemsetAsync(blk, 0, (acc_words + SPLITK_CNT_INTS / 2) * sizeof(long long), s));
     splitk_ws_floats = splitk_floats;
     splitk_ws = P<float>((size_t)splitk_floats);
     return 0;
@@ -93,6 +98,7 @@ struct FwdBase {
   void gemm(IGemmParams& p) {
     p.zero_page = zero;
     p.splitk_ws = splitk_ws; p.splitk_ws_floats = splitk_ws_floats;
+    p.splitk_cnt = splitk_cnt; p.splitk_cnt_ints = SPLITK_CNT_INTS;
     if (!dry && !rc) ok(launch_igemm(p, IGemmTune(), s));
   }
   // dense [M][K] x W[N][K]^T

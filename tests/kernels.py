@@ -42,7 +42,7 @@ def cast_f16(x, want_lo=False):
 
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
-          residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None,
+          residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None, fused_splitk=True,
           asym_pad=0, gn=None):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
     d = _lib.IGemmDesc()
@@ -74,9 +74,22 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
     ws = None
     if splitk != 1:
         M = B * Hout * Wout
-        ws = torch.empty((16 * M * N,), dtype=torch.float32, device=a0.device)
+        ws = torch.empty((16 * (M + 255) * (N + 255),), dtype=torch.float32, device=a0.device)
         d.splitk_ws = ws.data_ptr(); d.splitk_ws_floats = ws.numel()
+        if fused_splitk:
+            cnt = _splitk_counters(a0.device)
+            d.splitk_cnt = cnt.data_ptr(); d.splitk_cnt_ints = cnt.numel()
     _lib.check(_lib.load().sdmi_k_igemm(C.byref(d), _s()))
+
+
+_CNT = {}
+
+
+def _splitk_counters(dev):
+    """tile counters of the fused split-K reduction: zero once, the kernels leave them zero"""
+    if dev not in _CNT:
+        _CNT[dev] = torch.zeros((8192,), dtype=torch.int32, device=dev)
+    return _CNT[dev]
 
 
 def gn_acc_sums(acc):

@@ -212,9 +212,11 @@ def test_igemm_groupnorm_statistics(tile, splitk, B, H, W, C, N):
 @pytest.mark.parametrize('B,H,W,C,N,splitk,tile', [(2, 16, 16, 1280, 1280, 4, 2), (2, 8, 8, 1280, 1280, 15, 2),
                                                    (1, 5, 7, 256, 200, 3, 2), (2, 32, 32, 640, 640, 4, 3),
                                                    (1, 5, 7, 256, 200, 2, 0)])
-def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile):
-    """SD-sized split-K convs (hundreds of blocks on all XCDs write slabs, the reduce kernel sums them in split order):
-    value, partial tiles, the per-batch row vector, and 4 bit-identical repeats."""
+@pytest.mark.parametrize('fused', [True, False])
+def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
+    """SD-sized split-K convs (hundreds of blocks on all XCDs write slabs; the last block of a tile -- fused -- or the
+    reduce kernel sums them in split order): value, partial tiles, the per-batch row vector, 4 bit-identical repeats, and
+    the two reductions agree to rounding."""
     g = _g(77)
     a = _rand16((B * H * W, C), g)
     w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(9 * C))
@@ -228,12 +230,17 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile):
     for rep in range(4):
         out = torch.full((B * H * W, N), float('nan'), device=DEV)
         K.igemm(a_d, wp, N, B, H, W, H, W, 3, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=out,
-                splitk=splitk, tile=tile)
+                splitk=splitk, tile=tile, fused_splitk=fused)
         outs.append(out)
+    other = torch.full((B * H * W, N), float('nan'), device=DEV)
+    K.igemm(a_d, wp, N, B, H, W, H, W, 3, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=other,
+            splitk=splitk, tile=tile, fused_splitk=not fused)
     torch.cuda.synchronize()
-    assert K.report(f'igemm splitk-sd splitk{splitk} tile{tile} M{B * H * W} N{N}', outs[0], ref, 3e-4) < 3e-4
+    assert K.report(f'igemm splitk-sd splitk{splitk} tile{tile} M{B * H * W} N{N} fused={fused}', outs[0], ref, 3e-4) < 3e-4
     for o in outs[1:]:
         assert torch.equal(o, outs[0])
+    # (same split order; the epilogues add bias / row vector / residual in a different association: a few ulp)
+    assert (other - outs[0]).abs().max().item() <= 4e-6 * ref.abs().max().item()
 
 
 def test_igemm_split_fp16_1x1():
@@ -354,6 +361,9 @@ ATTN_CASES = [
     (40, 8, 256, 256), (40, 8, 4096, 4096), (80, 8, 1024, 1024), (160, 8, 256, 256), (160, 8, 64, 64),
     (40, 8, 256, 77), (80, 8, 64, 77), (160, 8, 64, 77), (32, 2, 16, 16), (64, 2, 4, 4), (128, 2, 100, 77),
     (40, 2, 200, 130), (64, 2, 96, 96),
+    # >= 512 keys: the software-pipelined kernel (odd / even tile counts, ragged last tile, every head dim it serves)
+    (40, 8, 600, 577), (80, 4, 300, 512), (64, 2, 130, 1000), (32, 2, 64, 640), (40, 2, 2304, 2304), (80, 2, 100, 1016),
+    (40, 2, 96, 520), (160, 2, 576, 576), (128, 2, 64, 777),
 ]
 
 
@@ -369,6 +379,7 @@ def test_attention(d, heads, nq, nkv):
     # a few large scores so the online-softmax rescale path is exercised (guide rule 26)
     q[0, 0] *= 6.0
     k[0, nkv - 1] *= 6.0
+    k[0, nkv // 2] *= 5.0
     scale = d ** -0.5
     sim = torch.bmm(q.float(), k.float().transpose(1, 2)) * scale
     ref = torch.bmm(sim.softmax(-1), v.float())
