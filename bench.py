@@ -161,6 +161,65 @@ def offline_traffic(kernel_class):
     return None
 
 
+def traffic_pass(out_json=None, keep_dir=None):
+    """`bench.py --traffic-pass`: HBM bytes per launch of every kernel class of one UNet call, measured: two rocprofv3
+    PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, no trace domains beside the kernel trace, as
+    MI355X_MICROARCH.md prescribes) over tools/prof_shapes.py, FETCH_SIZE doubled (gfx950 counts 64-byte requests in
+    its 32-byte unit), summed per kernel family and written to profiles/traffic_rNN.json, which the default run reads
+    for `roofline.traffic`.  Needs rocprofv3 and a GPU; takes ~1 minute."""
+    import glob
+    import sqlite3
+    import subprocess
+    import tempfile
+    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r02.json')
+    work = keep_dir or tempfile.mkdtemp(prefix='sdmi_traffic_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
+    per = {}
+    for ctr in ('FETCH_SIZE', 'WRITE_SIZE'):
+        d = os.path.join(work, ctr)
+        cmd = ['rocprofv3', '--pmc', ctr, '-d', d, '-o', 'pmc', '--', sys.executable, os.path.join(ROOT, 'tools', 'prof_shapes.py')]
+        r = subprocess.run(cmd, env=env, cwd='/tmp', capture_output=True, text=True, timeout=900)
+        if r.returncode != 0:
+            raise SystemExit(f'rocprofv3 --pmc {ctr} failed:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}')
+        for f in glob.glob(os.path.join(d, '**', '*_results.db'), recursive=True):
+            con = sqlite3.connect(f)
+            tabs = [r_[0] for r_ in con.execute("select name from sqlite_master where type='table'")]
+            pick = lambda key: [t for t in tabs if key in t][0]
+            q = (f"select s.kernel_name, sum(p.value), count(distinct p.event_id) from {pick('pmc_event')} p "
+                 f"join {pick('info_pmc')} i on p.pmc_id = i.id join {pick('kernel_dispatch')} k on p.event_id = k.event_id "
+                 f"join {pick('kernel_symbol')} s on k.kernel_id = s.id where i.name = '{ctr}' group by s.kernel_name")
+            for name, total, launches in con.execute(q):
+                e = per.setdefault(name, {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
+                e[ctr] += float(total)            # rocprofv3 reports these two derived counters in KiB
+                e['launches'] = max(e['launches'], int(launches))
+            con.close()
+
+    def family(name):
+        for key, fam in (('igemm_kernel', 'igemm_family'), ('conv3halo_kernel', 'igemm_family'), ('attn', 'attention'),
+                         ('splitk_reduce', 'splitk_reduce'), ('gn_apply', 'groupnorm'), ('gn_stats', 'groupnorm'),
+                         ('layernorm', 'layernorm')):
+            if key in name:
+                return fam
+        return None
+    kernels = {}
+    for name, e in per.items():
+        fam = family(name)
+        if fam is None or not e['launches']:
+            continue
+        k = kernels.setdefault(fam, {'launches': 0, 'fetch_kb_x2': 0.0, 'write_kb': 0.0})
+        k['launches'] += e['launches']
+        k['fetch_kb_x2'] += 2.0 * e['FETCH_SIZE']
+        k['write_kb'] += e['WRITE_SIZE']
+    for k in kernels.values():       # per launch, in MB (the keys offline_traffic() reads)
+        k['fetch_mb_x2'] = k.pop('fetch_kb_x2') / 1024.0 / k['launches']
+        k['write_mb'] = k.pop('write_kb') / 1024.0 / k['launches']
+    doc = {'source': 'bench.py --traffic-pass: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over '
+                     'tools/prof_shapes.py (model build + UNet calls, CFG batch 2, 64x64)', 'kernels': kernels}
+    with open(out_json, 'w') as f:
+        json.dump(doc, f, indent=1, sort_keys=True)
+    print(json.dumps({'traffic_pass': out_json, 'kernels': kernels}))
+
+
 def usable_cores():
     """Host cores this process may actually use: min(affinity mask, cgroup v2/v1 CPU quota) -- the GPU boxes report
     256 logical CPUs but run the job under a 16-CPU quota, where 256 torch threads are ~300x slower than 16."""
@@ -180,25 +239,51 @@ def usable_cores():
     return n
 
 
+def reference_unet():
+    """The real reference UNetModel (ldm/modules/diffusionmodules/openaimodel.py) when its sources are visible -- the build
+    container has them under /root/reference (or $SD_REFERENCE); a GPU box does not.  Returns a callable
+    (x, t, context) -> eps with the oracle's synthetic SD-v1 weights loaded strict=True, or None."""
+    ref = os.environ.get('SD_REFERENCE', '/root/reference')
+    if not os.path.isdir(os.path.join(ref, 'ldm')):
+        return None
+    try:
+        from oracle.make_golden import _import_reference
+        from oracle.plan import SD_V1
+        from oracle.weights import make_state_dict
+        UNetModel = _import_reference()[0]
+        m = UNetModel(**SD_V1.ref_kwargs()).eval()
+        m.load_state_dict(make_state_dict(SD_V1, 0), strict=True)
+        return lambda x, t, c: m(x, t, context=c)
+    except Exception as e:        # a missing dependency of the reference: fall back to the restatement, and say so
+        print(f'[bench] reference UNet not importable ({type(e).__name__}: {e}); CPU baseline uses the oracle port', file=sys.stderr)
+        return None
+
+
 def cpu_baseline(n_unet_calls=2):
-    """The oracle (fp32 CPU restatements of the reference UNet and first-stage decoder) on the host cores; bounded sample:
-    `n_unet_calls` UNet calls at the full workload shape (CFG batch 2, latent 64x64) and one VAE decode, extrapolated
-    to 51 calls + 1 decode per image."""
+    """The CPU comparator on the host cores: the reference's own UNetModel when /root/reference is visible (kind
+    "reference"), else the oracle (fp32 CPU restatements of the reference UNet; kind "port"); the first-stage decode is
+    the oracle's in both cases.  Bounded sample: `n_unet_calls` UNet calls at the full workload shape (CFG batch 2, latent
+    64x64) and one VAE decode, extrapolated to 51 calls + 1 decode per image."""
     from oracle import unet_ref
     from oracle.plan import SD_V1
     from oracle.weights import make_inputs, make_state_dict
     from oracle import vae_ref
     cores = usable_cores()
     torch.set_num_threads(cores)
-    sd = make_state_dict(SD_V1, 0)
     x, t, ctx = make_inputs(SD_V1, 2, 64, 64, seed=1)
+    ref_fn = reference_unet()
+    kind = 'reference' if ref_fn is not None else 'port'
+    if ref_fn is None:
+        sd = make_state_dict(SD_V1, 0)
+        ref_fn = lambda x_, t_, c_: unet_ref.unet_forward(sd, SD_V1, x_, t_, c_)
     times = []
-    for _ in range(n_unet_calls):
-        t0 = time.perf_counter()
-        unet_ref.unet_forward(sd, SD_V1, x, t, ctx)
-        times.append(time.perf_counter() - t0)
-        if times[-1] > 20.0:          # keep the sample bounded on slow hosts
-            break
+    with torch.no_grad():
+        for _ in range(n_unet_calls):
+            t0 = time.perf_counter()
+            ref_fn(x, t, ctx)
+            times.append(time.perf_counter() - t0)
+            if times[-1] > 20.0:          # keep the sample bounded on slow hosts
+                break
     t_unet = min(times)
     vsd = vae_ref.make_vae_state_dict(vae_ref.SD_VAE, 0, encoder=False)
     z = vae_ref.make_vae_inputs(vae_ref.SD_VAE, 1, 64, 64, seed=1) * 0.18215
@@ -206,8 +291,9 @@ def cpu_baseline(n_unet_calls=2):
     vae_ref.decode_first_stage(vsd, vae_ref.SD_VAE, z)
     t_vae = time.perf_counter() - t0
     s_per_image = 51 * t_unet + t_vae
-    return {'value': 1.0 / s_per_image, 'unit': 'images/s', 'cores': cores, 'kind': 'port',
-            'sample': f'{len(times)} oracle UNet call(s) (fp32, {cores} threads, B=2, 64x64 latent: {t_unet:.2f} s each) + 1 VAE decode '
+    who = 'reference UNetModel' if kind == 'reference' else 'oracle UNet'
+    return {'value': 1.0 / s_per_image, 'unit': 'images/s', 'cores': cores, 'kind': kind,
+            'sample': f'{len(times)} {who} call(s) (fp32, {cores} threads, B=2, 64x64 latent: {t_unet:.2f} s each) + 1 VAE decode '
                       f'({t_vae:.2f} s), extrapolated to 51 calls + 1 decode = {s_per_image:.1f} s/image'}
 
 
@@ -254,7 +340,15 @@ def main():
     ap.add_argument('--workload', choices=sorted(WORKLOADS), default='txt2img512',
                     help='txt2img512 = BASELINE.json configs[1] (the headline metric, default); txt2img768 = configs[3]; '
                          'img2img512 = configs[4]')
+    ap.add_argument('--traffic-pass', action='store_true',
+                    help='measure HBM bytes per launch with rocprofv3 PMC passes and write profiles/traffic_r02.json (then exit)')
+    ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the CPU comparator (no GPU needed) and exit')
     args = ap.parse_args()
+    if args.traffic_pass:
+        return traffic_pass()
+    if args.cpu_baseline_only:
+        print(json.dumps({'cpu_baseline': cpu_baseline(1)}))
+        return
     wl = WORKLOADS[args.workload]
     LAT = wl['latent']
 

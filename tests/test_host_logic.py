@@ -250,11 +250,12 @@ def test_plugin_seam_against_the_real_reference():
     assert hasattr(mine, 'encode') and hasattr(mine, 'freeze')
 
 
-def test_committed_bench_line_has_the_contract_keys():
-    """profiles/bench_r01.json is the JSON line `python bench.py` printed on the MI355X: the driver's contract keys, the
+@pytest.mark.parametrize('name', ['bench_r01.json', 'bench_r02.json'])
+def test_committed_bench_line_has_the_contract_keys(name):
+    """profiles/bench_rNN.json is the JSON line `python bench.py` printed on the MI355X: the driver's contract keys, the
     roofline / cpu_baseline objects, and internally consistent numbers."""
     import json
-    d = json.load(open(os.path.join(ROOT, 'profiles', 'bench_r01.json')))
+    d = json.load(open(os.path.join(ROOT, 'profiles', name)))
     for k in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
               'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
         assert k in d, k
@@ -269,3 +270,34 @@ def test_committed_bench_line_has_the_contract_keys():
     for k in ('value', 'unit', 'cores', 'kind', 'sample'):
         assert k in c, k
     assert c['kind'] in ('port', 'reference') and c['unit'] == d['unit'] and d['value'] / c['value'] >= 8.0   # north_star: >= 8x
+
+
+def test_cpu_baseline_kind_follows_the_visibility_of_the_reference(monkeypatch):
+    """bench.py's CPU comparator is the reference's own UNetModel where /root/reference is visible (kind "reference": the
+    build container, recorded in profiles/cpu_baseline_reference_r02.json) and the oracle port where it is not (a GPU
+    box: nothing under bench.py may read /root/reference there)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location('sdmi_bench', os.path.join(ROOT, 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    monkeypatch.setenv('SD_REFERENCE', '/nonexistent/reference')
+    assert bench.reference_unet() is None
+    rec = json.load(open(os.path.join(ROOT, 'profiles', 'cpu_baseline_reference_r02.json')))['cpu_baseline']
+    assert rec['kind'] == 'reference' and rec['unit'] == 'images/s' and 0 < rec['value'] < 0.1
+
+
+def test_gpu_side_never_reads_the_reference_tree():
+    """/root/reference does not exist on a GPU box: the `-m gpu` tests and smoke() must not mention it, and bench.py may
+    only probe it behind an existence check (the CPU comparator's `kind`)."""
+    import glob
+    for f in glob.glob(os.path.join(ROOT, 'tests', 'test_*_gpu.py')) + [os.path.join(ROOT, 'tests', 'kernels.py')]:
+        text = open(f).read()             # (docstrings may mention the path; code must not use it or import from it)
+        for needle in ("'/root/reference", '"/root/reference', 'SD_REFERENCE', 'import ldm', 'from ldm'):
+            assert needle not in text, (f, needle)
+    entry = open(os.path.join(ROOT, '__graft_entry__.py')).read()
+    smoke = entry[entry.index('def smoke'):]
+    assert '/root/reference' not in smoke and 'SD_REFERENCE' not in smoke
+    bench = open(os.path.join(ROOT, 'bench.py')).read()
+    body = bench[bench.index('def reference_unet'):bench.index('def cpu_baseline')]
+    assert 'os.path.isdir' in body and bench.count("'/root/reference'") == body.count("'/root/reference'") == 1
