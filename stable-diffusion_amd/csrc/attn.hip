@@ -297,7 +297,13 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   constexpr int NCH = (D + 63) / 64;   // 64-half chunks of a K row
   constexpr int KROWS = NCH * 64, VROWS = DVT * 32;
   constexpr int STAGE = (KROWS + VROWS) * 128;
-  constexpr int PK = NCH * 8, PV = DVT * 4, PT = PK + PV;          // DMA pieces (8 rows x 128 B each) per tile
+  // The V^T tile has VROWS = 32 * DVT rows in LDS; when D is not a multiple of 32 (d = 40, 80) the rows D .. VROWS-1 are
+  // padding.  They are written once (never DMA'd), row D with ONES: O^T row D = sum_k P[q][k] is then the softmax
+  // denominator, accumulated by the MFMAs (from the same fp16-rounded P as the numerator, rescaled with O) -- the loop
+  // carries no row-sum instructions.
+  constexpr bool ONES = VROWS > D;
+  constexpr int PK = NCH * 8, PV = ONES ? D / 8 : DVT * 4, PT = PK + PV;   // DMA pieces (8 rows x 128 B each) per tile
+  static_assert(D % 8 == 0, "a DMA piece is 8 rows");
   constexpr int PPW = (PT + NW - 1) / NW;                          // per wave (the surplus re-issues the last piece)
   static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS budget");
 
@@ -368,6 +374,13 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
+  if (ONES) {
+    for (int e = tid; e < NS * (VROWS - D) * 8; e += NW * 64) {           // 16-byte chunks of the padding rows of every stage
+      const int st = e / ((VROWS - D) * 8), rc = e - st * ((VROWS - D) * 8), row = D + (rc >> 3);
+      const unsigned one2 = row == D ? 0x3C003C00u : 0u;                   // fp16 1.0 pairs
+      *(u32x4*)(smem + st * STAGE + (KROWS + row) * 128 + (rc & 7) * 16) = u32x4{one2, one2, one2, one2};
+    }
+  }
   const float sc = p.scale * 1.4426950408889634f;   // scores are compared / exponentiated in log2 units
 
   const int nt = (p.nkv + KVT - 1) / KVT;
@@ -419,7 +432,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
       asm volatile("; rescale" ::: "memory");
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       m_run = m_new;
-      l_run *= alpha;
+      if (!ONES) l_run *= alpha;
 #pragma unroll
       for (int dt = 0; dt < DVT; ++dt)
 #pragma unroll
@@ -436,9 +449,9 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
         const f32x2 pv = {ABL == 3 ? e[0] : __builtin_amdgcn_exp2f(e[0]), ABL == 3 ? e[1] : __builtin_amdgcn_exp2f(e[1])};
         s[kvb][r] = pv[0];
         s[kvb][r + 1] = pv[1];
-        psum2 += pv;
+        if (!ONES) psum2 += pv;
       }
-    l_run += psum2[0] + psum2[1];
+    if (!ONES) l_run += psum2[0] + psum2[1];
 
     // ---- O^T += V^T P^T ----
 #pragma unroll
@@ -466,7 +479,15 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   }
   wait_dma<0>();
 
-  const float l_tot = sum_across_halves(l_run);
+  float l_tot;
+  if (ONES) {            // row D of O^T: tile D / 32, register and lane half of local row D % 32
+    constexpr int rl = D % 32, r_l = (rl & 3) + 4 * (rl >> 3), lg_l = (rl >> 2) & 1;
+    float a = o[D / 32][r_l], b = a;
+    swap_halves(a, b);                                   // a = {a.lo, b.lo}, b = {a.hi, b.hi}
+    l_tot = lg_l == 0 ? a : b;
+  } else {
+    l_tot = sum_across_halves(l_run);
+  }
   const float inv = 1.0f / l_tot;
   const int q = q0 + l31;
   if (q < p.nq) {

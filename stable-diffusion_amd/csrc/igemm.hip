@@ -1359,7 +1359,7 @@ static Tuner g_tuner;
 static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_split) {
   std::vector<TuneChoice> out;
   const int nkt = p.K / BK;
-  static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16};
+  static const int splits[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};     // 5 / 10: halo tiles only (20 / 40 channel chunks)
   for (int t = 0; t < SDMI_NUM_TILES; ++t) {
     const TileCfg& c = kTiles[t];
     if (tile_is_halo(t) && !halo_supported(p, c.bm)) continue;
@@ -1372,6 +1372,7 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
     if ((long)c.bm > 2L * p.M && c.bm > 64) continue;                  // tile mostly padding
     if ((long)c.bn > 2L * p.N && c.bn > 64) continue;
     for (int sk : splits) {
+      if ((sk == 5 || sk == 10) && !tile_is_halo(t)) continue;
       if (sk > 1) {
         if (p.splitk != 0 || !can_split) break;                        // caller pinned the split
         if (nkt / sk < 4) break;                                       // >= 4 k-tiles per split
