@@ -161,7 +161,7 @@ def offline_traffic(kernel_class):
     return None
 
 
-def traffic_pass(out_json=None, keep_dir=None):
+def traffic_pass(out_json=None, keep_dir=None, also=None):
     """`bench.py --traffic-pass`: HBM bytes per launch of every kernel class of one UNet call, measured: two rocprofv3
     PMC passes (FETCH_SIZE, WRITE_SIZE -- separate runs, no trace domains beside the kernel trace, as
     MI355X_MICROARCH.md prescribes) over tools/prof_shapes.py, FETCH_SIZE doubled (gfx950 counts 64-byte requests in
@@ -183,11 +183,8 @@ def traffic_pass(out_json=None, keep_dir=None):
             raise SystemExit(f'rocprofv3 --pmc {ctr} failed:\n{r.stdout[-2000:]}\n{r.stderr[-2000:]}')
         for f in glob.glob(os.path.join(d, '**', '*_results.db'), recursive=True):
             con = sqlite3.connect(f)
-            tabs = [r_[0] for r_ in con.execute("select name from sqlite_master where type='table'")]
-            pick = lambda key: [t for t in tabs if key in t][0]
-            q = (f"select s.kernel_name, sum(p.value), count(distinct p.event_id) from {pick('pmc_event')} p "
-                 f"join {pick('info_pmc')} i on p.pmc_id = i.id join {pick('kernel_dispatch')} k on p.event_id = k.event_id "
-                 f"join {pick('kernel_symbol')} s on k.kernel_id = s.id where i.name = '{ctr}' group by s.kernel_name")
+            q = ("select kernel_name, sum(value), count(distinct dispatch_id) from counters_collection "
+                 f"where counter_name = '{ctr}' group by kernel_name")
             for name, total, launches in con.execute(q):
                 e = per.setdefault(name, {'launches': 0, 'FETCH_SIZE': 0.0, 'WRITE_SIZE': 0.0})
                 e[ctr] += float(total)            # rocprofv3 reports these two derived counters in KiB
@@ -215,8 +212,9 @@ def traffic_pass(out_json=None, keep_dir=None):
         k['write_mb'] = k.pop('write_kb') / 1024.0 / k['launches']
     doc = {'source': 'bench.py --traffic-pass: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over '
                      'tools/prof_shapes.py (model build + UNet calls, CFG batch 2, 64x64)', 'kernels': kernels}
-    with open(out_json, 'w') as f:
-        json.dump(doc, f, indent=1, sort_keys=True)
+    for path in [out_json] + ([also] if also else []):
+        with open(path, 'w') as f:
+            json.dump(doc, f, indent=1, sort_keys=True)
     print(json.dumps({'traffic_pass': out_json, 'kernels': kernels}))
 
 
@@ -342,10 +340,11 @@ def main():
                          'img2img512 = configs[4]')
     ap.add_argument('--traffic-pass', action='store_true',
                     help='measure HBM bytes per launch with rocprofv3 PMC passes and write profiles/traffic_r02.json (then exit)')
+    ap.add_argument('--traffic-out', default=None, help='second copy of the --traffic-pass JSON (e.g. under gpurun_out/)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the CPU comparator (no GPU needed) and exit')
     args = ap.parse_args()
     if args.traffic_pass:
-        return traffic_pass()
+        return traffic_pass(also=args.traffic_out)
     if args.cpu_baseline_only:
         print(json.dumps({'cpu_baseline': cpu_baseline(1)}))
         return
@@ -362,6 +361,8 @@ def main():
     device = torch.device('cuda', local_rank if world > 1 else 0)
     torch.cuda.set_device(device)
 
+    if not args.no_roofline:
+        os.environ.setdefault('SDMI_PROF_SHAPES', '1')     # per-shape class names in the profiling call (read once by libsdmi)
     ld, unet, vae = build_gpu_model(device, vae_kind=args.vae, vae_parts=wl['vae_parts'])
     sampler = PLMSSamplerHIP(ld) if wl['sampler'] == 'plms' else DDIMSamplerHIP(ld)
     # synthetic conditioning / start codes; the seed depends on the GLOBAL prompt index only
@@ -440,6 +441,27 @@ def main():
                     'mfma_classes_tflops': sum(r['flops'] for r in mfma) / (sum(r['ms'] for r in mfma) * 1e-3) / 1e12
                     if mfma else None,
                 }
+                # per-class table: the GEMM shapes folded back into their tile instantiation (the per-shape names are
+                # only needed for the weight-streaming entry below)
+                import re as _re
+                folded = {}
+                for r in table:
+                    key = _re.sub(r'_M\d+_N\d+_K\d+.*$', '', r['name'])
+                    f_ = folded.setdefault(key, {'name': key, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
+                    for k_ in ('launches', 'ms', 'flops', 'bytes'):
+                        f_[k_] += r[k_]
+                out['roofline']['per_class'] = [cls(r) for r in sorted(folded.values(), key=lambda r: -r['ms'])]
+                # the weight-streaming GEMMs (M <= 128 rows, i.e. the 8x8 level: every weight byte is a first touch and
+                # there are only 0.13 MFLOP per weight byte): bytes = weights + activations + outputs, against HBM peak
+                ws = [r for r in fam if (lambda m: m and int(m.group(1)) <= 128)(_re.search(r'_M(\d+)_N', r['name']))]
+                if ws:
+                    wb, wms, wn = sum(r['bytes'] for r in ws), sum(r['ms'] for r in ws), sum(r['launches'] for r in ws)
+                    gbs_w = wb / (wms * 1e-3) / 1e9
+                    out['roofline_weight_stream'] = {
+                        'bound': 'hbm', 'kernel': 'igemm_kernel on the M <= 128 shapes (split-K partial GEMMs, reduce kernels not included)',
+                        'launches_per_unet_call': wn, 'avg_launch_ms': wms / wn, 'achieved': gbs_w, 'peak': HBM_PEAK_GBS,
+                        'unit': 'GB/s', 'frac': gbs_w / HBM_PEAK_GBS, 'traffic': None,
+                        'algorithmic_gbytes_per_launch': wb / wn / 1e9}
                 # second entry: the dominant HBM-bound kernel class (norms / reduce / casts), against the HBM peak
                 hbm = [r for r in table if not r['name'].startswith(('igemm', 'conv3halo', 'attn'))]
                 if hbm:

@@ -53,7 +53,7 @@ static void run(const std::vector<unsigned char*>& bufs, unsigned* sink, int N, 
   hipEventRecord(e1, 0); hipDeviceSynchronize();
   float ms; hipEventElapsedTime(&ms, e0, e1);
   const double us = ms * 1e3 / bufs.size(), gb = (double)N * K * 2 / 1e9;
-  printf("%-6s depth %2d splits %2d blocks %4d : %6.1f us per matrix = %5.2f TB/s\n", PANEL ? "panel" : "rows", DEPTH, splits, blocks, us, gb / us * 1e6 / 1e3 / 1e3);
+  printf("%-6s depth %2d splits %2d blocks %4d : %6.1f us per matrix = %5.2f TB/s\n", PANEL ? "panel" : "rows", DEPTH, splits, blocks, us, gb / us * 1e3);
 }
 
 int main() {
