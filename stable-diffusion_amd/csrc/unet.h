@@ -48,6 +48,11 @@ struct FwdBase {
   float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
   int* splitk_cnt = nullptr;                          // one int per output tile of a split-K GEMM (igemm.hip)
   static constexpr int SPLITK_CNT_INTS = 8192;
+  // side stream (optional): work that is independent of the main chain for a while -- the ResBlock's 1x1 skip convolution
+  // runs beside conv1 / GroupNorm 2 -- is enqueued there between two events; it has its own split-K slabs
+  hipStream_t side = nullptr;
+  hipEvent_t* side_ev = nullptr; int side_nev = 0, side_next = 0;
+  float* splitk_ws2 = nullptr; int64_t splitk_ws2_floats = 0;
   int rc = 0;
   GnPlan* plan = nullptr;         // null: GroupNorm statistics always by the statistics kernel (first stage, text encoder)
   int n_acts = 0;
@@ -92,7 +97,28 @@ struct FwdBase {
     if (!dry) SDMI_HIP_OK(hipMemsetAsync(blk, 0, (acc_words + SPLITK_CNT_INTS / 2) * sizeof(long long), s));
     splitk_ws_floats = splitk_floats;
     splitk_ws = P<float>((size_t)splitk_floats);
+    splitk_ws2_floats = splitk_floats / 2;               // (always: the workspace size must not depend on the side stream)
+    splitk_ws2 = P<float>((size_t)splitk_ws2_floats);
     return 0;
+  }
+  // fork: the side stream continues from this point of the main stream; join: the main stream waits for the side stream
+  hipEvent_t next_side_event() { hipEvent_t e = side_ev[side_next]; side_next = (side_next + 1) % side_nev; return e; }
+  void fork_side() {
+    if (dry || rc || !side) return;
+    hipEvent_t e = next_side_event();
+    if (hipEventRecord(e, s) != hipSuccess || hipStreamWaitEvent(side, e, 0) != hipSuccess) ok(fail("side stream fork failed"));
+  }
+  void join_side() {
+    if (dry || rc || !side) return;
+    hipEvent_t e = next_side_event();
+    if (hipEventRecord(e, side) != hipSuccess || hipStreamWaitEvent(s, e, 0) != hipSuccess) ok(fail("side stream join failed"));
+  }
+  void gemm_side(IGemmParams& p) {        // like gemm(), on the side stream (falls back to the main stream without one)
+    if (!side) { gemm(p); return; }
+    p.zero_page = zero;
+    p.splitk_ws = splitk_ws2; p.splitk_ws_floats = splitk_ws2_floats;
+    p.splitk_cnt = nullptr; p.splitk_cnt_ints = 0;
+    if (!dry && !rc) ok(launch_igemm(p, IGemmTune(), side));
   }
 
   void gemm(IGemmParams& p) {
@@ -231,6 +257,8 @@ class UNet {
   size_t slot_bytes(const WeightSlot& s) const;
   int ensure_ctx_cache(int B, int Lctx);
   GnPlan gn_plan_;           // GroupNorm-statistics fusion plan of the current forward (rebuilt by its dry pass)
+  bool side_stream_ = false;    // SDMI_SIDE_STREAM=1: ResBlock skip convolutions on a side stream (measured 3 % slower)
+  hipStream_t side_ = nullptr; hipEvent_t side_ev_[32] = {};
   bool fuse_gn_stats_ = true;   // SDMI_FUSE_GN_STATS=0: every GroupNorm runs its own statistics kernel (A/B, debugging)
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
