@@ -93,6 +93,7 @@ struct IGemmParams {
   // its counter).  Slabs then need splitk * round_up(M, BM) * round_up(N, BN) floats.
   int* splitk_cnt = nullptr; int splitk_cnt_ints = 0;
   int splitk_fused = 0;                                // set by the launcher
+  int tile_n_fastest = 0;                              // set by the launcher: tile numbering inside an XCD's range
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
   // optional (plain mode): GroupNorm(32) statistics of the finished output for up to two consuming GroupNorms -- the
   // output's channels are channels [gn_cbase, gn_cbase + N) of that GroupNorm's (possibly concatenated) input with

@@ -452,8 +452,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   const int tiles_mn = tiles_m * tiles_n;
   const int split = wgid / tiles_mn;
   const int tmn = wgid - split * tiles_mn;
-  const int tile_n = tmn / tiles_m;
-  const int tile_m = tmn - tile_n * tiles_m;
+  // which operand an XCD keeps to itself: an XCD runs a contiguous range of tile numbers, and its L2 is private.  With more
+  // A bytes than weight bytes (M > N) the range walks N fastest -- few row panels of A, every weight panel -- so A is
+  // fetched from the fabric by ONE XCD instead of all eight; the weight-heavy shapes (M <= N) keep walking M fastest.
+  int tile_m, tile_n;
+  if (p.tile_n_fastest) { tile_m = tmn / tiles_n; tile_n = tmn - tile_m * tiles_n; }
+  else { tile_n = tmn / tiles_m; tile_m = tmn - tile_n * tiles_m; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int nkt = p.K / BK;
   const int kt_begin = split * kt_per_split;
@@ -770,8 +774,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
   const int tiles_mn = tiles_m * tiles_n;
   const int split = wgid / tiles_mn;
   const int tmn = wgid - split * tiles_mn;
-  const int tile_n = tmn / tiles_m;
-  const int tile_m = tmn - tile_n * tiles_m;
+  // which operand an XCD keeps to itself: an XCD runs a contiguous range of tile numbers, and its L2 is private.  With more
+  // A bytes than weight bytes (M > N) the range walks N fastest -- few row panels of A, every weight panel -- so A is
+  // fetched from the fabric by ONE XCD instead of all eight; the weight-heavy shapes (M <= N) keep walking M fastest.
+  int tile_m, tile_n;
+  if (p.tile_n_fastest) { tile_m = tmn / tiles_n; tile_n = tmn - tile_m * tiles_n; }
+  else { tile_n = tmn / tiles_m; tile_m = tmn - tile_n * tiles_m; }
   const int m0 = tile_m * BM, n0 = tile_n * BN;
   const int nch = (p.c0 + p.c1 + p.c2) / BK;
   const int c_begin = split * chunks_per_split;
@@ -1084,6 +1092,14 @@ static unsigned long long div_magic(int d) {      // ceil(2^40 / d), see fast_di
   return (one + (unsigned long long)d - 1) / (unsigned long long)d;
 }
 
+// see the kernels' tile numbering: true = an XCD owns rows of A (M > N), false = it owns weight panels
+static int tile_order_n_fastest(const IGemmParams& p) {
+  static const int env_order = env_int("SDMI_TILE_ORDER", 0);      // 0 auto, 1 always M fastest (round-1 order), 2 always N fastest
+  if (env_order == 1) return 0;
+  if (env_order == 2) return 1;
+  return p.M > p.N ? 1 : 0;
+}
+
 // split-K slabs a (tile, split) choice needs, in floats: register-order slabs of whole tiles when the reduction is fused
 // into the GEMM (see igemm_epilogue), [split][M][N] for the separate reduce kernel
 static bool splitk_fusable(const IGemmParams& p, int bm, int bn) {
@@ -1105,6 +1121,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int nsplit = cdiv(nkt, kt_per_split);
   IGemmParams q = p;
   q.splitk = nsplit;
+  q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
@@ -1191,6 +1208,7 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   const int nsplit = cdiv(nch, chunks_per_split);
   IGemmParams q = p;
   q.splitk = nsplit;
+  q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
