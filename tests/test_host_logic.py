@@ -301,3 +301,26 @@ def test_gpu_side_never_reads_the_reference_tree():
     bench = open(os.path.join(ROOT, 'bench.py')).read()
     body = bench[bench.index('def reference_unet'):bench.index('def cpu_baseline')]
     assert 'os.path.isdir' in body and bench.count("'/root/reference'") == body.count("'/root/reference'") == 1
+
+
+def test_committed_tuning_table_is_well_formed():
+    """stable-diffusion_amd/tune_gfx950.txt fixes the (tile, split-K) choice per GEMM shape -- and with the split the summation
+    order, i.e. the exact output bits: every line must parse, name an existing tile and a split the kernels support, and use
+    the halo-staged conv tiles (14..17) only for stride-1 3x3 convolutions."""
+    path = os.path.join(ROOT, 'stable-diffusion_amd', 'tune_gfx950.txt')
+    rows = [l.split() for l in open(path) if l.strip() and not l.startswith('#')]
+    assert len(rows) >= 300
+    seen = set()
+    for r in rows:
+        assert len(r) == 11, r
+        M, N, K, ksize, stride, up, mode, req, tile, splitk = (int(x) for x in r[:10])
+        us = float(r[10])
+        assert M > 0 and N > 0 and K > 0 and K % 64 == 0 and ksize in (1, 3) and stride in (1, 2) and up in (0, 1) and mode in (0, 1, 2)
+        assert 0 <= tile < 22 and 1 <= splitk <= 16 and us > 0
+        if 14 <= tile <= 17:
+            assert ksize == 3 and stride == 1 and up == 0, r
+        if mode == 1:
+            assert splitk == 1, r          # the GEGLU epilogue pairs columns inside a tile: never split
+        key = tuple(r[:8])
+        assert key not in seen, key
+        seen.add(key)
