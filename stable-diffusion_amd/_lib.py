@@ -3,7 +3,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsdmi.so')
+LIB_PATH = os.environ.get('SDMI_LIB_PATH') or os.path.join(_HERE, 'libsdmi.so')     # (override: same-box A/B of two builds)
 
 c_f32p = C.c_void_p     # device pointers travel as integers (tensor.data_ptr())
 c_ptr = C.c_void_p
