@@ -11,8 +11,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
-OBJ = os.path.join(HERE, 'build')
-LIB = os.path.join(HERE, 'libsdmi.so')
+# A second library next to the product one (instrumented builds, two-build A/Bs through SDMI_LIB_PATH):
+#   SDMI_CXXFLAGS='-DSDMI_IGEMM_TIMING' SDMI_LIB_OUT=libsdmi_timing.so python stable-diffusion_amd/build.py
+EXTRA = os.environ.get('SDMI_CXXFLAGS', '').split()
+LIB = os.path.join(HERE, os.environ.get('SDMI_LIB_OUT', 'libsdmi.so'))
+OBJ = os.path.join(HERE, 'build' if os.path.basename(LIB) == 'libsdmi.so' else 'build_' + os.path.splitext(os.path.basename(LIB))[0])
 SOURCES = ['igemm.hip', 'range.hip', 'conv3gn.hip', 'attn.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable']
@@ -32,7 +35,7 @@ def _stamp():
             with open(os.path.join(root, fn), 'rb') as f:
                 h.update(fn.encode())
                 h.update(f.read())
-    h.update(' '.join(FLAGS).encode())
+    h.update(' '.join(FLAGS + EXTRA).encode())
     return h.hexdigest()
 
 
@@ -51,7 +54,7 @@ def build(force=False, verbose=True):
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
         extra = ['-ffp-contract=off'] if src == 'sampler.hip' else []    # bit-exact fp32 op order (see sampler.hip)
-        cmd = [hipcc] + FLAGS + extra + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        cmd = [hipcc] + FLAGS + EXTRA + extra + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')

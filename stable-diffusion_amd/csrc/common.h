@@ -92,6 +92,9 @@ struct IGemmParams {
   // epilogue -- no reduce kernel.  Counters: one int per output tile, zero before the first launch (the last block resets
   // its counter).  Slabs then need splitk * round_up(M, BM) * round_up(N, BN) floats.
   int* splitk_cnt = nullptr; int splitk_cnt_ints = 0;
+#ifdef SDMI_IGEMM_TIMING
+  long long* dbg_times = nullptr;                      // timing build only: 4 s_memtime stamps per workgroup
+#endif
   int splitk_fused = 0;                                // set by the launcher
   int tile_n_fastest = 0;                              // set by the launcher: tile numbering inside an XCD's range
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)

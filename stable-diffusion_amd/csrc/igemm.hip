@@ -45,6 +45,15 @@ namespace {
 
 constexpr int BK = 64;
 
+// Per-workgroup phase stamps (s_memtime at kernel entry, k-loop entry, k-loop exit, kernel exit) exist only in a build with
+// -DSDMI_IGEMM_TIMING (SDMI_CXXFLAGS=-DSDMI_IGEMM_TIMING SDMI_LIB_OUT=... python stable-diffusion_amd/build.py; tools/igemm_timing.py):
+// the product library carries no trace of them.
+#ifdef SDMI_IGEMM_TIMING
+#define SDMI_STAMP(name) const long long name = p.dbg_times ? (long long)__builtin_readcyclecounter() : 0
+#else
+#define SDMI_STAMP(name)
+#endif
+
 // exact-erf GELU (F.gelu default, attention.py:43).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e.
 // 3 orders of magnitude below the fp16 rounding of the GEGLU output) -- the libm erff costs ~3x more VALU.
 __device__ __forceinline__ float gelu_erf(float x) {
@@ -465,6 +474,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   if (kt_begin >= kt_end) return;
 
   const int tid = threadIdx.x;
+  SDMI_STAMP(dbg_t0);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int cpos = tid & 7;                      // chunk position inside the LDS row
@@ -647,6 +657,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
       for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i], b[j], acc[i][j], 0, 0, 0);
   };
 
+  SDMI_STAMP(dbg_t1);
   if constexpr (DMA) {
     // Software pipeline (one raw s_barrier per k-tile, NS - 1 LDS-DMA tiles in flight across it):
     //   * fragments are double buffered in registers: the ds_reads of k-step s + 1 are issued before the MFMAs of
@@ -723,7 +734,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   }
 
   // ---- epilogue ------------------------------------------------------------------------------------
+  SDMI_STAMP(dbg_t2);
   igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
+#ifdef SDMI_IGEMM_TIMING
+  if (p.dbg_times && tid == 0) {        // (where a workgroup's time goes; blocks that return early in the epilogue are not stamped)
+    long long* d = p.dbg_times + 4 * (size_t)blockIdx.x;
+    d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = (long long)__builtin_readcyclecounter();
+  }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -1575,7 +1593,47 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     SDMI_CHECK(splitk_ws_need(p, kTiles[tile].bm, kTiles[tile].bn, splitk) <= p.splitk_ws_floats, "split-K workspace too small");
   }
   if (ev0) SDMI_HIP_OK(hipEventRecord(ev0, stream));
+#ifdef SDMI_IGEMM_TIMING
+  static const char* dbg_path = getenv("SDMI_IGEMM_TIMING");       // debug: per-workgroup phase timing appended to this file
+  static long long* dbg_buf = nullptr;
+  IGemmParams pd = p;
+  if (dbg_path && !tile_is_halo(tile)) {
+    if (!dbg_buf) SDMI_HIP_OK(hipMalloc((void**)&dbg_buf, 4 * 16384 * sizeof(long long)));
+    SDMI_HIP_OK(hipMemsetAsync(dbg_buf, 0, 4 * 16384 * sizeof(long long), stream));
+    pd.dbg_times = dbg_buf;
+  }
+  const int rc = launch_tile(tile, pd, dma, splitk, stream);
+  if (dbg_path && pd.dbg_times && rc == 0) {
+    SDMI_HIP_OK(hipStreamSynchronize(stream));
+    std::vector<long long> h(4 * 16384);
+    SDMI_HIP_OK(hipMemcpy(h.data(), dbg_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
+    std::vector<long long> pro, loop, epi, start;
+    long long tmin = 0, tmax = 0;
+    for (int b = 0; b < 16384; ++b) {
+      const long long* d = &h[4 * b];
+      if (d[3] == 0) continue;
+      pro.push_back(d[1] - d[0]); loop.push_back(d[2] - d[1]); epi.push_back(d[3] - d[2]);
+      if (start.empty() || d[0] < tmin) tmin = d[0];
+      if (d[3] > tmax) tmax = d[3];
+      start.push_back(d[0]);
+    }
+    if (!pro.empty()) {
+      auto med = [](std::vector<long long>& v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; };
+      auto mx = [](std::vector<long long>& v) { return *std::max_element(v.begin(), v.end()); };
+      long long late = 0;
+      for (long long t : start) late = std::max(late, t - tmin);
+      if (FILE* f = fopen(dbg_path, "a")) {
+        const int nkt_split = (p.K / BK + std::max(splitk, 1) - 1) / std::max(splitk, 1);
+        fprintf(f, "M%d N%d K%d k%d mode%d tile%d split%d blocks%zu k-tiles/block %d | shader cycles: span %lld last-start %lld | median prologue %lld loop %lld epilogue %lld | max loop %lld | loop cycles per k-tile %.1f\n",
+                p.M, p.N, p.K, p.ksize, p.mode, tile, splitk, pro.size(), nkt_split, tmax - tmin, late, med(pro), med(loop), med(epi), mx(loop),
+                (double)med(loop) / nkt_split);
+        fclose(f);
+      }
+    }
+  }
+#else
   const int rc = launch_tile(tile, p, dma, splitk, stream);
+#endif
   if (rc == 0 && range_check_enabled()) {          // debug: fp16 outputs of this GEMM (MFMA operands of the next)
     const char* what = p.mode == EPI_GEGLU ? "igemm GEGLU output" : (p.mode == EPI_HEADS ? "igemm q/k/v^T" : "igemm fp16 output");
     if (p.mode == EPI_HEADS) {
