@@ -51,15 +51,34 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = _hipcc()
 
+    def headers_hash():
+        h = hashlib.sha256()
+        for root in (CSRC, os.path.join(os.path.dirname(HERE), 'include')):
+            for fn in sorted(os.listdir(root)):
+                if fn.endswith('.h'):
+                    with open(os.path.join(root, fn), 'rb') as f:
+                        h.update(fn.encode())
+                        h.update(f.read())
+        return h.hexdigest()
+
+    hdrs = headers_hash()
+
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
         extra = ['-ffp-contract=off'] if src == 'sampler.hip' else []    # bit-exact fp32 op order (see sampler.hip)
         cmd = [hipcc] + FLAGS + EXTRA + extra + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
+        # per-object cache: igemm.hip alone takes minutes, so an object is rebuilt only when its source, a header or the flags changed
+        with open(os.path.join(CSRC, src), 'rb') as f:
+            key = hashlib.sha256(f.read() + hdrs.encode() + ' '.join(cmd).encode()).hexdigest()
+        if not force and os.path.exists(obj) and os.path.exists(obj + '.key') and open(obj + '.key').read() == key:
+            return obj
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f'hipcc failed for {src}:\n{r.stdout}\n{r.stderr}')
         if verbose and r.stderr.strip():
             print(r.stderr, file=sys.stderr)
+        with open(obj + '.key', 'w') as f:
+            f.write(key)
         return obj
 
     with cf.ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:

@@ -96,6 +96,7 @@ struct IGemmParams {
   long long* dbg_times = nullptr;                      // timing build only: 4 s_memtime stamps per workgroup
 #endif
   int splitk_fused = 0;                                // set by the launcher
+  int epi_vec = 0;                                     // set by the launcher: 16-byte epilogue (pointer / pitch alignment checked there)
   int tile_n_fastest = 0;                              // set by the launcher: tile numbering inside an XCD's range
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
   // optional (plain mode): GroupNorm(32) statistics of the finished output for up to two consuming GroupNorms -- the

@@ -19,7 +19,7 @@
 //     MFMAs of tile t run.
 //   * epilogues: +bias[n] +rowvec[batch][n] (time-embedding add) +fp32 residual, fp32 and/or fp16 store;
 //     GEGLU (value * gelu_erf(gate), weights pre-interleaved in 32-row groups); per-head scatter of
-//     q / k / v^T for the attention kernel; split-K via fp32 atomics onto a pre-initialised output.
+//     q / k / v^T for the attention kernel; split-K into per-split fp32 slabs summed in a fixed order (reduce kernel).
 //   * blockIdx is remapped so that each XCD (private L2) owns a contiguous range of tiles.
 #include <dlfcn.h>
 
@@ -101,6 +101,42 @@ __device__ __forceinline__ int fast_div(int m, unsigned long long magic) {
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
+// ---- accumulator slabs through LDS (the 16-byte epilogues) -------------------------------------------------------------
+// A wave owns one LDS region of 32 rows x LSTR floats.  slab_put writes the wave's TN 32x32 MFMA accumulator tiles of one
+// 32-row slab in the C/D register layout (col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)); afterwards lane l
+// reads 16 bytes at row q * RPI + l / LPR, column 4 * (l % LPR): WTN / 4 lanes cover a row, a wave instruction covers RPI
+// whole rows (128- or 256-byte runs in memory).  Only the owning wave touches its region, and a wave's LDS operations execute
+// in order, so a drained lgkmcnt (plus a compiler barrier) is all the synchronisation the turn-around needs.
+template <int WTN> constexpr int SLAB_LPR = WTN / 4;       // lanes per row
+template <int WTN> constexpr int SLAB_RPI = 64 / (WTN / 4);  // rows per wave instruction
+template <int WTN> constexpr int SLAB_NPASS = 32 / (64 / (WTN / 4));
+// row pitch in floats: 16-byte aligned rows with 4 banks of skew where the LDS allows it (not the 2-stage 128x128 8-wave tile)
+template <int NWAVES, int WTN, int LDS_BYTES>
+constexpr int SLAB_LSTR = (NWAVES * 32 * (WTN + 4) * 4 <= LDS_BYTES) ? WTN + 4 : WTN;
+template <int NWAVES, int WTN, int LDS_BYTES>
+__device__ __forceinline__ float* slab_base(unsigned char* smem, int wave) {
+  static_assert(WTN == 32 || WTN == 64, "lane mapping of the 16-byte epilogue");
+  static_assert(NWAVES * 32 * SLAB_LSTR<NWAVES, WTN, LDS_BYTES> * 4 <= LDS_BYTES, "LDS too small for the epilogue slabs");
+  return (float*)smem + wave * (32 * SLAB_LSTR<NWAVES, WTN, LDS_BYTES>);
+}
+template <int TN, int LSTR>
+__device__ __forceinline__ void slab_put(float* wl, const f32x16 (&a)[TN], int l31, int lg) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) wl[((r & 3) + 8 * (r >> 2) + 4 * lg) * LSTR + j * 32 + l31] = a[j][r];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+template <int TN, int LSTR>
+__device__ __forceinline__ void slab_get(const float* wl, f32x16 (&a)[TN], int l31, int lg) {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a[j][r] = wl[((r & 3) + 8 * (r >> 2) + 4 * lg) * LSTR + j * 32 + l31];
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
+
 // The epilogue shared by the GEMM kernels (generic implicit GEMM and the halo-staged 3x3 convolution): accumulators of the
 // wave's TM x TN MFMA tiles -> bias / time-embedding row vector / residual / fp32 + fp16 (+ split-fp16 low half) stores,
 // GEGLU, per-head q / k / v^T scatter, split-K slabs, GroupNorm statistics.  `smem` = the block's LDS (free at this point:
@@ -112,6 +148,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
   constexpr int NT = WARPS_M * WARPS_N * 64;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
+  constexpr int LSTR = SLAB_LSTR<WARPS_M * WARPS_N, WTN, LDS_BYTES>;       // row pitch of the 16-byte epilogues' LDS slabs
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
@@ -180,7 +217,51 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
     float* slab = atomic ? (p.splitk_ws + (size_t)split * p.M * p.N) : nullptr;
     const int b_first = m0 / HWout;
     const bool one_batch = ((m0 + BM - 1) / HWout == b_first);
-    if (full && one_batch) {
+    if (full && one_batch && p.epi_vec && !atomic) {
+      // ---- 16-byte epilogue: every wave turns its 32 x WTN accumulator slabs through its own LDS region (the tile buffers are
+      // free now) so that a lane owns 4 CONSECUTIVE columns of a row: one dwordx4 residual load, one dwordx4 fp32 store and
+      // one 8-byte fp16 store per 4 values instead of a dword / short access each -- the same bytes in a quarter of the
+      // vector-memory instructions.  The arithmetic is the scalar path's, value by value ((acc + column term) + residual):
+      // results are bit-identical.  Measured (profiles/epilogue_16byte_r02.txt): -3 ... -12 % epilogue cycles here, -45 ... -70 %
+      // on the q / k scatter below; the split-K slab stores and the GEGLU epilogue got SLOWER through the LDS turn (stores
+      // without loads in front of them are fire-and-forget either way) and keep their register-layout stores.
+      __syncthreads();                                     // every wave's LDS-DMA has landed and nobody reads the tiles any more
+      float* const wl = slab_base<WARPS_M * WARPS_N, WTN, LDS_BYTES>(smem, wave);
+      const int rl = lane / SLAB_LPR<WTN>, c4 = (lane % SLAB_LPR<WTN>) * 4;
+      f32x4 colv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) colv = *(const f32x4*)(p.bias + nw + c4);
+      if (p.rowvec) colv += *(const f32x4*)(p.rowvec + (size_t)b_first * p.ld_rowvec + nw + c4);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        slab_put<TN, LSTR>(wl, acc[i], l31, lg);
+        constexpr int NP = SLAB_NPASS<WTN>, RPI = SLAB_RPI<WTN>;
+        f32x4 resv[NP];
+        if (p.residual) {
+#pragma unroll
+          for (int q = 0; q < NP; ++q)
+            resv[q] = *(const f32x4*)(p.residual + (size_t)(mw + i * 32 + q * RPI + rl) * p.ldr + nw + c4);
+        } else {
+#pragma unroll
+          for (int q = 0; q < NP; ++q) resv[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int q = 0; q < NP; ++q) {
+          const int row = q * RPI + rl;
+          float* const lp = wl + row * LSTR + c4;
+          const f32x4 v = *(const f32x4*)lp + colv + resv[q];
+          const size_t ro = (size_t)(mw + i * 32 + row) * p.ldo + nw + c4;
+          if (p.out_f32) *(f32x4*)(p.out_f32 + ro) = v;
+          const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+          if (p.out_f16) *(f16x4*)(p.out_f16 + ro) = h;
+          if (p.out_lo)
+            *(f16x4*)(p.out_lo + ro) = f16x4{(f16)(v[0] - (float)h[0]), (f16)(v[1] - (float)h[1]), (f16)(v[2] - (float)h[2]),
+                                            (f16)(v[3] - (float)h[3])};
+          if (p.gn_n > 0) *(f32x4*)lp = v;                 // final values back for the statistics below
+        }
+        if (p.gn_n > 0) slab_get<TN, LSTR>(wl, acc[i], l31, lg);
+        else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // slab reads done before the next slab_put overwrites them
+      }
+    } else if (full && one_batch) {
       if (atomic) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -378,6 +459,54 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
         }
       return;
     }
+    if (p.bias) {                          // q/k/v projections with a bias (CLIP text model); the UNet's have none
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = nw + j * 32 + l31;
+        const float bv = n < p.N ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
+      }
+    }
+    // row-layout segments (q, k: [token][dh]) through the LDS slabs: a lane stores 4 consecutive dd of a token as one 8-byte
+    // quad instead of 4 shorts.  The launcher checked segC % 32 == 0 (a 32-column block lies in one segment) and dh % 4 == 0.
+    // Transposed segments (v^T) keep the register path below: there a lane already owns 4 consecutive tokens.
+    const bool vecq = full && p.epi_vec;
+    if (vecq) {
+      __syncthreads();
+      float* const wl = slab_base<WARPS_M * WARPS_N, WTN, LDS_BYTES>(smem, wave);
+      const int rl = lane / SLAB_LPR<WTN>, c4 = (lane % SLAB_LPR<WTN>) * 4;
+      const int n = nw + c4;
+      const int seg = n / p.segC;
+      const int c = n - seg * p.segC;
+      const int head = c / p.dh;
+      const int dd = c - head * p.dh;
+      f16* const dst = p.seg_dst[seg];
+      const bool rowseg = p.seg_kind[seg] == 0;
+      bool any_row = false;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) any_row |= p.seg_kind[(nw + j * 32) / p.segC] == 0;     // wave-uniform
+      if (any_row) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          slab_put<TN, LSTR>(wl, acc[i], l31, lg);
+          if (rowseg) {
+#pragma unroll
+            for (int q = 0; q < SLAB_NPASS<WTN>; ++q) {
+              const int row = q * SLAB_RPI<WTN> + rl;
+              const int m = mw + i * 32 + row;
+              const int b = m / p.ntok;
+              const int tok = m - b * p.ntok;
+              const f32x4 a = *(const f32x4*)(wl + row * LSTR + c4);
+              *(f16x4*)(dst + (((size_t)b * p.heads + head) * p.ntok + tok) * p.dh + dd) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next slab_put overwrites them
+        }
+      }
+    }
     // lane = output column (seg, head, dd); registers 4q..4q+3 = 4 consecutive rows (tokens)
     const bool vec4 = (p.ntok % 4 == 0) && (p.ntok_pad % 4 == 0);
 #pragma unroll
@@ -390,13 +519,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
       const int dd = c - head * p.dh;
       f16* dst = p.seg_dst[seg];
       const int kind = p.seg_kind[seg];
-      if (p.bias) {                        // q/k/v projections with a bias (CLIP text model); the UNet's have none
-        const float bv = p.bias[n];
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-      }
+      if (vecq && kind == 0) continue;       // stored above
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -1131,6 +1254,20 @@ static int64_t splitk_ws_need(const IGemmParams& p, int bm, int bn, int nsplit) 
   return (int64_t)nsplit * p.M * p.N;
 }
 
+// May this launch use the 16-byte epilogues (igemm_epilogue: unsplit plain mode, q / k of the per-head scatter)?  They need
+// 16-byte aligned fp32 rows and 8-byte aligned fp16 rows at every multiple-of-4 column, and for the scatter 32-column blocks
+// that lie inside one segment.
+// SDMI_EPI_VEC=0 keeps the dword / short epilogues (A/B; the results are bit-identical).
+static int epi_vec_ok(const IGemmParams& p) {
+  if (!env_int("SDMI_EPI_VEC", 1) || p.N % 4) return 0;      // (read per launch: the tests flip it between two calls)
+  auto al = [](const void* q, uintptr_t a) { return ((uintptr_t)q & (a - 1)) == 0; };
+  if (p.mode == EPI_PLAIN)
+    return p.ldo % 4 == 0 && al(p.out_f32, 16) && al(p.out_f16, 8) && al(p.out_lo, 8) && al(p.bias, 16) &&
+           al(p.rowvec, 16) && p.ld_rowvec % 4 == 0 && al(p.residual, 16) && p.ldr % 4 == 0;
+  if (p.mode == EPI_GEGLU) return 0;
+  return p.segC % 32 == 0 && p.dh % 4 == 0 && al(p.bias, 16) && al(p.seg_dst[0], 8) && al(p.seg_dst[1], 8) && al(p.seg_dst[2], 8);
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
@@ -1141,6 +1278,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   q.splitk = nsplit;
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
+  q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
@@ -1228,6 +1366,7 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   q.splitk = nsplit;
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
+  q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);

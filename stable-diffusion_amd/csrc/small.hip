@@ -61,6 +61,63 @@ __global__ void __launch_bounds__(256) small_linear_kernel(const float* in, int 
   }
 }
 
+// The same product with the (activated) input rows staged ONCE per block in LDS and all of a lane's weight quads in flight
+// before the first FMA.  In small_linear_kernel every wave re-evaluates SiLU of all B x K inputs (an expf and an IEEE
+// division per element) and waits for one 16-byte load at a time: on the 20160 x 1280 emb_layers matrix that is VALU- and
+// latency-bound (~45 us for 103 MB).  Same expressions in the same per-lane order: the results are bit-identical
+// (tests/test_kernels_gpu.py); the three launches of a UNet call 78.7 -> 52.7 us (profiles/small_kernels_r02.txt).
+// KI = ceil(K / 256) weight quads per lane; dynamic LDS = B * K floats.
+template <int KI>
+__global__ void __launch_bounds__(512) small_linear_lds_kernel(const float* in, int ld_in, const float* w, const float* bias,
+                                                               float* out, int ld_out, int B, int N, int K, int silu_in) {
+  extern __shared__ __attribute__((aligned(16))) float sl_xs[];       // [B][K]
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int idx = tid * 4; idx < B * K; idx += 512 * 4) {              // K % 4 == 0: a quad stays inside one row
+    const int b = idx / K, k = idx - b * K;
+    f32x4 xv = *(const f32x4*)(in + (size_t)b * ld_in + k);
+    if (silu_in) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xv[j] = xv[j] / (1.0f + expf(-xv[j]));
+    }
+    *(f32x4*)(sl_xs + idx) = xv;
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 8 + (tid >> 6);
+  if (n >= N) return;
+  const float* wr = w + (size_t)n * K;
+  f32x4 wv[KI];
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = lane * 4 + i * 256;
+    wv[i] = k < K ? __builtin_nontemporal_load((const f32x4*)(wr + k)) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  float acc[SL_MAXB];
+#pragma unroll
+  for (int b = 0; b < SL_MAXB; ++b) acc[b] = 0.f;
+#pragma unroll
+  for (int i = 0; i < KI; ++i) {
+    const int k = lane * 4 + i * 256;
+    if (k < K) {
+#pragma unroll
+      for (int b = 0; b < SL_MAXB; ++b) {
+        if (b < B) {
+          const f32x4 xv = *(const f32x4*)(sl_xs + b * K + k);
+          acc[b] += wv[i][0] * xv[0] + wv[i][1] * xv[1] + wv[i][2] * xv[2] + wv[i][3] * xv[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int b = 0; b < SL_MAXB; ++b) {
+    if (b < B) {
+      float v = acc[b];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      if (lane == 0) out[(size_t)b * ld_out + n] = v + (bias ? bias[n] : 0.f);
+    }
+  }
+}
+
 constexpr int CI_PIX = 16;
 constexpr int CI_MAXK = 9 * 16;   // Cin <= 16
 // x NCHW fp32 -> out NHWC fp32, 3x3 pad 1
@@ -138,6 +195,85 @@ __global__ void __launch_bounds__(256) conv_out_kernel(const float* h, const flo
       for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
       if (lane == 0) out[(((size_t)b * Cout + n) * H + y) * W + x] = v + (bias ? bias[n] : 0.f);
     }
+  }
+}
+
+// The same convolution with one wave per COP = 4 consecutive pixels of an image row: a weight quad is loaded once per wave
+// and tap instead of once per pixel and tap, and an input pixel once per wave and kernel row instead of once per output
+// pixel and tap (27 vector loads per pixel instead of 90: the one-wave-per-pixel kernel moves 4.6 KB of weights through
+// the vector-memory path per pixel and tap row).  Every accumulator sees its terms in conv_out_kernel's order -- taps
+// ascending, channel quads ascending inside a tap, out-of-image taps skipped; the compiler contracts the FMAs differently,
+// so the two kernels agree to a few fp32 ulp, not bit for bit (this is the last operation of the UNet / first stage:
+// nothing downstream rounds the difference up).  UNet `out` head: 41.8 -> 22.9 us (profiles/small_kernels_r02.txt).
+// NOUT = 4 or 8 (>= Cout), Cin <= 512 (two channel passes of 64 lanes x 4), W % COP == 0.
+constexpr int COP = 4;
+template <int NOUT>
+__global__ void __launch_bounds__(256) conv_out4_kernel(const float* h, const float* w, const float* bias, float* out, int B,
+                                                        int H, int W, int Cin, int Cout) {
+  const int lane = threadIdx.x & 63;
+  const int g = blockIdx.x * 4 + (threadIdx.x >> 6);       // pixel group
+  const int wq = W / COP;
+  if (g >= B * H * wq) return;
+  const int b = g / (H * wq), rem = g - b * H * wq, y = rem / wq, x0 = (rem - y * wq) * COP;
+  const int K = 9 * Cin;
+  const int c0 = lane * 4, c1 = lane * 4 + 256;
+  const bool v0 = c0 < Cin, v1 = c1 < Cin;
+  float acc[COP][NOUT];
+#pragma unroll
+  for (int p = 0; p < COP; ++p)
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n) acc[p][n] = 0.f;
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky) {
+    const int iy = y + ky - 1;
+    if (iy < 0 || iy >= H) continue;                       // (wave-uniform)
+    f32x4 xa[COP + 2], xb[COP + 2];                        // input columns x0 - 1 .. x0 + COP of this row, both channel passes
+#pragma unroll
+    for (int j = 0; j < COP + 2; ++j) {
+      const int ix = x0 - 1 + j;
+      const bool in = ix >= 0 && ix < W;
+      const float* src = h + ((size_t)(b * H + iy) * W + (in ? ix : 0)) * Cin;
+      xa[j] = (in && v0) ? *(const f32x4*)(src + c0) : zero;
+      xb[j] = (in && v1) ? *(const f32x4*)(src + c1) : zero;
+    }
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const int tap = ky * 3 + kx;
+      f32x4 wa[NOUT], wb[NOUT];
+#pragma unroll
+      for (int n = 0; n < NOUT; ++n) {
+        const float* wp = w + (size_t)(n < Cout ? n : 0) * K + tap * Cin;
+        wa[n] = v0 ? *(const f32x4*)(wp + c0) : zero;
+        wb[n] = v1 ? *(const f32x4*)(wp + c1) : zero;
+      }
+#pragma unroll
+      for (int p = 0; p < COP; ++p) {
+        const int ix = x0 + p + kx - 1;
+        if (ix < 0 || ix >= W) continue;                   // (wave-uniform) out-of-image tap: skipped, as in conv_out_kernel
+        const f32x4 xv = xa[p + kx], xw = xb[p + kx];
+        if (v0) {
+#pragma unroll
+          for (int n = 0; n < NOUT; ++n) acc[p][n] += wa[n][0] * xv[0] + wa[n][1] * xv[1] + wa[n][2] * xv[2] + wa[n][3] * xv[3];
+        }
+        if (v1) {
+#pragma unroll
+          for (int n = 0; n < NOUT; ++n) acc[p][n] += wb[n][0] * xw[0] + wb[n][1] * xw[1] + wb[n][2] * xw[2] + wb[n][3] * xw[3];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) {
+    f32x4 r;
+#pragma unroll
+    for (int p = 0; p < COP; ++p) {
+      float v = acc[p][n];
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+      r[p] = v + ((bias && n < Cout) ? bias[n] : 0.f);
+    }
+    if (lane == 0 && n < Cout) *(f32x4*)(out + (((size_t)b * Cout + n) * H + y) * W + x0) = r;
   }
 }
 
@@ -321,8 +457,17 @@ int launch_small_linear(const float* in, int ld_in, const float* w, const float*
   SDMI_CHECK(B >= 1 && B <= SL_MAXB, "small_linear: batch must be 1..8");
   SDMI_CHECK(K % 4 == 0 && ld_in % 4 == 0, "small_linear: K % 4");
   ProfScope ps("small_linear_f32", 2.0 * B * (double)N * K, (double)N * K * 4.0, s);
-  hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, ld_in, w, bias, out, ld_out, B, N, K,
-                     silu_in);
+  const char* e_lds = getenv("SDMI_SMALL_LDS");                  // A/B knob, read per launch (3 per UNet call); bit-identical results
+  const int env_lds = e_lds ? atoi(e_lds) : 1;
+  const size_t lds = (size_t)B * K * sizeof(float);
+  const bool al16 = ((((uintptr_t)in | (uintptr_t)w) & 15) == 0);
+  if (env_lds && K <= 1280 && lds <= 64 * 1024 && al16) {           // every input row of the block in LDS, <= 5 weight quads per lane
+    if (K <= 512) hipLaunchKernelGGL(small_linear_lds_kernel<2>, dim3(cdiv(N, 8)), dim3(512), lds, s, in, ld_in, w, bias, out, ld_out, B, N, K, silu_in);
+    else hipLaunchKernelGGL(small_linear_lds_kernel<5>, dim3(cdiv(N, 8)), dim3(512), lds, s, in, ld_in, w, bias, out, ld_out, B, N, K, silu_in);
+  } else {
+    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, ld_in, w, bias, out, ld_out, B, N, K,
+                       silu_in);
+  }
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -342,7 +487,16 @@ int launch_conv_out(const float* h, const float* w, const float* bias, float* ou
   ProfScope ps("conv_out_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
   // (an LDS-resident-weights variant, 32 pixels per block, was measured at 169 us vs 64 us: one wave per pixel keeps 1024
   // independent waves in flight, which this latency-bound fp32 kernel needs more than it needs fewer weight re-reads)
-  hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+  const char* e_co4 = getenv("SDMI_CONV_OUT4");                  // A/B knob, read per launch (1 per UNet call)
+  const int env_co4 = e_co4 ? atoi(e_co4) : 1;
+  const bool al16 = ((((uintptr_t)h | (uintptr_t)w | (uintptr_t)out) & 15) == 0);
+  if (env_co4 && W % COP == 0 && Cin <= 512 && al16) {       // (out rows of W floats at x0 % 4 == 0: 16-byte aligned stores)
+    const int groups = B * H * (W / COP);
+    if (Cout <= 4) hipLaunchKernelGGL(conv_out4_kernel<4>, dim3(cdiv(groups, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+    else hipLaunchKernelGGL(conv_out4_kernel<8>, dim3(cdiv(groups, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+  } else {
+    hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+  }
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -341,6 +341,58 @@ def test_igemm_head_scatter_splitk(ntok, d, heads, Kd, splitk):
     assert all(torch.equal(x, y_) for x, y_ in zip(outs[0], outs[1]))
 
 
+@pytest.mark.parametrize('tile', [0, 3, 5, 6, 7, 8, 9, 10, 12, 13, 14, 15, 16, 17])
+def test_igemm_16_byte_epilogue_bit_identical(tile, monkeypatch):
+    """16-byte epilogues (accumulators turned through LDS, igemm.hip) against the dword / short ones (SDMI_EPI_VEC=0), same
+    launch otherwise: plain mode with bias + row vector + residual + fp32 and fp16 outputs + GroupNorm statistics, split-K
+    slabs, GEGLU and the per-head scatter -- every output bit for bit."""
+    g = _g(123)
+    B, H, W, C, N = 2, 16, 16, 128, 256
+    M = B * H * W
+    a = _rand16((M, C), g).to(DEV)
+    w = _rand16((N, C, 3, 3), g, 1.0 / math.sqrt(9 * C))
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    bias, rowvec, resid = torch.randn(N, generator=g).to(DEV), torch.randn(B, N, generator=g).to(DEV), torch.randn(M, N, generator=g).to(DEV)
+    halo = 14 <= tile <= 17
+
+    def run_all():
+        res = []
+        for splitk in (1, 2):
+            o32 = torch.full((M, N), float('nan'), device=DEV)
+            o16 = torch.zeros((M, N), dtype=torch.float16, device=DEV)
+            acc0 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+            K.igemm(a, wp, N, B, H, W, H, W, 3, 1, 0, bias=bias, rowvec=rowvec, residual=resid, out_f32=o32, out_f16=o16,
+                    splitk=splitk, tile=tile, fused_splitk=False, gn=[(acc0, N // 32, 0)])
+            res += [o32, o16, acc0]
+        if not halo:
+            wl = _rand16((N, C), g0, 1.0 / math.sqrt(C)).to(DEV)
+            if tile in (0, 3, 6, 7, 8, 9, 12, 13):                    # GEGLU: waves own an even number of 32-column tiles
+                wg, bg = K.pack_geglu(wl.float(), bias)
+                og = torch.zeros((M, N // 2), dtype=torch.float16, device=DEV)
+                K.igemm(a, wg, N, 1, M, 1, M, 1, bias=bg, out_f16=og, mode=1, tile=tile)
+                res.append(og)
+            heads, d = 2, 32                                          # q | k | v^T, 3 x 64 columns = 192 of the 256 weight rows
+            ntok = H * W
+            q = torch.zeros((B * heads, ntok, d), dtype=torch.float16, device=DEV)
+            k = torch.zeros_like(q)
+            vt = torch.zeros((B * heads, d, ntok), dtype=torch.float16, device=DEV)
+            K.igemm(a, wl[:192].contiguous(), 192, B, ntok, 1, ntok, 1, mode=2, tile=tile, bias=bias[:192].contiguous(),
+                    heads=dict(segs=[(q, 0), (k, 0), (vt, 1)], heads=heads, dh=d, ntok=ntok, ntok_pad=ntok, segC=heads * d))
+            res += [q, k, vt]
+        torch.cuda.synchronize()
+        return res
+
+    g0 = _g(5)
+    monkeypatch.setenv('SDMI_EPI_VEC', '1')
+    r1 = run_all()
+    g0 = _g(5)
+    monkeypatch.setenv('SDMI_EPI_VEC', '0')
+    r0 = run_all()
+    assert len(r0) == len(r1) and all(torch.isfinite(x.float()).all() for x in r1)
+    for i, (x, y) in enumerate(zip(r1, r0)):
+        assert torch.equal(x, y), (i, float((x.float() - y.float()).abs().max()))
+
+
 def test_igemm_sd_l0_conv_shape():
     """The dominant SD-v1 shape: 320->320 3x3 at 64x64, CFG batch 2."""
     g = _g(8)
@@ -531,6 +583,45 @@ def test_conv_in_out():
     ref2 = F.conv2d(h, w2, b2, padding=1)
     out2 = K.conv_out(_nhwc(h).reshape(B, H * W, 320).to(DEV), w2.to(DEV), b2.to(DEV), B, H, W)
     assert K.report('conv_out', out2, ref2, 2e-5) < 2e-5
+
+
+@pytest.mark.parametrize('B,H,W,Cin,Cout', [(2, 9, 12, 320, 4), (1, 16, 16, 128, 3), (2, 8, 8, 512, 8), (1, 5, 20, 64, 4), (2, 64, 64, 320, 4)])
+def test_conv_out_4_pixels_per_wave(B, H, W, Cin, Cout, monkeypatch):
+    """conv_out4_kernel (one wave per 4 pixels of a row; UNet `out` head openaimodel.py:533-537, first-stage conv_out
+    model.py:553-566, encoder conv_out) vs F.conv2d, and against the one-wave-per-pixel kernel: same terms in the same order
+    per accumulator, but the compiler contracts the FMAs differently -- a few fp32 ulp, on the last op of the path."""
+    g = _g(31)
+    h = torch.randn(B, Cin, H, W, generator=g)
+    w2 = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b2 = torch.randn(Cout, generator=g) * 0.1
+    ref = F.conv2d(h, w2, b2, padding=1)
+    hd = _nhwc(h).reshape(B, H * W, Cin).to(DEV)
+    monkeypatch.setenv('SDMI_CONV_OUT4', '1')
+    out4 = K.conv_out(hd, w2.to(DEV), b2.to(DEV), B, H, W).clone()
+    monkeypatch.setenv('SDMI_CONV_OUT4', '0')
+    out1 = K.conv_out(hd, w2.to(DEV), b2.to(DEV), B, H, W).clone()
+    torch.cuda.synchronize()
+    assert K.report(f'conv_out4 {B}x{Cin}x{H}x{W}->{Cout}', out4, ref, 2e-5) < 2e-5
+    assert float((out4 - out1).abs().max()) <= 4e-6
+
+
+@pytest.mark.parametrize('B,N,K_', [(2, 1280, 320), (2, 1280, 1280), (2, 20160, 1280), (5, 77, 64), (8, 640, 1280)])
+@pytest.mark.parametrize('silu', [0, 1])
+def test_small_linear_lds_staged(B, N, K_, silu, monkeypatch):
+    """small_linear_lds_kernel (activated input rows staged once per block, all weight quads of a lane in flight; time_embed and
+    the 22 emb_layers, openaimodel.py:506-511,218-224) vs F.linear, and bit for bit against the one-load-at-a-time kernel."""
+    g = _g(32)
+    w = torch.randn(N, K_, generator=g) / math.sqrt(K_)
+    b = torch.randn(N, generator=g) * 0.1
+    x = torch.randn(B, K_, generator=g) * 2
+    ref = F.linear(F.silu(x) if silu else x, w, b)
+    monkeypatch.setenv('SDMI_SMALL_LDS', '1')
+    o1 = K.small_linear(x.to(DEV), w.to(DEV), b.to(DEV), silu).clone()
+    monkeypatch.setenv('SDMI_SMALL_LDS', '0')
+    o0 = K.small_linear(x.to(DEV), w.to(DEV), b.to(DEV), silu).clone()
+    torch.cuda.synchronize()
+    assert K.report(f'small_linear lds B{B} N{N} K{K_} silu{silu}', o1, ref, 3e-5) < 3e-5
+    assert torch.equal(o1, o0)
 
 
 @pytest.mark.parametrize('mode', [0, 1, 2, 3, 4])

@@ -137,6 +137,25 @@ def test_batch_rows_are_independent(cfg_name, B, h, w):
     assert worst <= 2 * TOL
 
 
+@pytest.mark.parametrize('cfg_name,B,h,w', [('tiny', 2, 16, 16), ('small40', 2, 16, 16), ('sdv1', 2, 32, 32), ('sdv1', 2, 64, 64)])
+def test_16_byte_epilogues_are_bit_identical(cfg_name, B, h, w, monkeypatch):
+    """The GEMM epilogues that turn the accumulators through LDS and store 16 bytes per lane (igemm.hip, default) perform the
+    same arithmetic value by value as the dword / short epilogues (SDMI_EPI_VEC=0): eps must not change by one bit."""
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, 0)
+    x, t, ctx = make_inputs(cfg, B, h, w, seed=11)
+    monkeypatch.setenv('SDMI_EPI_VEC', '1')
+    e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_EPI_VEC', '0')
+    e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_EPI_VEC', '1')
+    e2 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(e1).all()
+    assert torch.equal(e1, e2)
+    assert torch.equal(e1, e0), float((e1 - e0).abs().max())
+
+
 def test_more_than_8_rows_is_chunked():
     """`txt2img.py --n_samples 5` is a CFG batch of 10: the library takes <= 8 rows per call, UNetModelHIP.forward splits the
     batch (rows are independent) -- bit-identical to calling the chunks by hand, with and without a pinned context."""
