@@ -51,25 +51,35 @@ def build(force=False, verbose=True):
         return LIB
     hipcc = _hipcc()
 
-    def headers_hash():
-        h = hashlib.sha256()
-        for root in (CSRC, os.path.join(os.path.dirname(HERE), 'include')):
-            for fn in sorted(os.listdir(root)):
-                if fn.endswith('.h'):
-                    with open(os.path.join(root, fn), 'rb') as f:
-                        h.update(fn.encode())
-                        h.update(f.read())
-        return h.hexdigest()
+    inc_dirs = (CSRC, os.path.join(os.path.dirname(HERE), 'include'))
 
-    hdrs = headers_hash()
+    def deps_hash(src):
+        """hash of the source and of the project headers it includes (transitively; `#include "..."` only)"""
+        import re
+        seen, todo, h = set(), [os.path.join(CSRC, src)], hashlib.sha256()
+        while todo:
+            path = todo.pop()
+            if path in seen:
+                continue
+            seen.add(path)
+            with open(path, 'rb') as f:
+                data = f.read()
+            h.update(os.path.basename(path).encode())
+            h.update(data)
+            for inc in re.findall(rb'^\s*#\s*include\s*"([^"]+)"', data, re.M):
+                for d in (os.path.dirname(path),) + inc_dirs:
+                    cand = os.path.join(d, inc.decode())
+                    if os.path.exists(cand):
+                        todo.append(os.path.normpath(cand))
+                        break
+        return h.hexdigest()
 
     def compile_one(src):
         obj = os.path.join(OBJ, os.path.splitext(src)[0] + '.o')
         extra = ['-ffp-contract=off'] if src == 'sampler.hip' else []    # bit-exact fp32 op order (see sampler.hip)
         cmd = [hipcc] + FLAGS + EXTRA + extra + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', os.path.join(CSRC, src), '-o', obj]
         # per-object cache: igemm.hip alone takes minutes, so an object is rebuilt only when its source, a header or the flags changed
-        with open(os.path.join(CSRC, src), 'rb') as f:
-            key = hashlib.sha256(f.read() + hdrs.encode() + ' '.join(cmd).encode()).hexdigest()
+        key = hashlib.sha256((deps_hash(src) + ' '.join(cmd)).encode()).hexdigest()
         if not force and os.path.exists(obj) and os.path.exists(obj + '.key') and open(obj + '.key').read() == key:
             return obj
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -102,47 +102,60 @@ __device__ __forceinline__ void gn_fold(const long long* acc, int b, int g, int 
   *rstd = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// floor(m / d) for 0 <= m, m * d < 2^40, magic = ceil(2^40 / d) (host computed; same scheme as igemm.hip's fast_div)
+__device__ __forceinline__ int gn_fast_div(int m, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
+}
+static unsigned long long gn_div_magic(int d) { return ((1ull << 40) + (unsigned long long)d - 1) / (unsigned long long)d; }
+
 // normalise (+SiLU); U channel quads per thread (U = 4 on first-stage-sized maps so the per-block statistics fold is
 // amortised); grid (blocks per batch row, B)
 template <int U>
-__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p) {
+__global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const unsigned long long magic_nq,
+                                                       const unsigned long long magic_cpg) {
   __shared__ float s_mean[32], s_rstd[32];
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
   const int nq = C / 4;
   const int b = blockIdx.y, tid = threadIdx.x;
+  // The activation quads (and their gamma / beta) are requested FIRST: they do not depend on the statistics, so their
+  // latency runs under the accumulator loads and the fp64 fold below instead of behind them (a block handles 256 * U quads:
+  // with U = 1 the fold's round trip was as long as the block's useful work).
+  const int64_t total = (int64_t)p.HW * nq;
+  const int64_t base = (int64_t)blockIdx.x * (256 * U) + tid;   // quad index inside this batch row
+  f32x4 v[U], ga[U], be[U]; size_t pix[U]; int ch[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {
+    const int64_t idx = base + u * 256;
+    if (idx < total) {
+      // (magic != 0: the launcher found the quad index small enough for the multiply-shift division -- the int64 division
+      // sequence was ~200 instructions in front of the first load)
+      const int64_t px = magic_nq ? (int64_t)gn_fast_div((int)idx, magic_nq) : idx / nq;
+      pix[u] = (size_t)b * p.HW + (size_t)px;
+      ch[u] = (int)(idx - px * nq) * 4;
+      v[u] = load_cat4(p.x0, p.x1, p.c0, p.c1, pix[u], ch[u]);
+      ga[u] = *(const f32x4*)(p.gamma + ch[u]);
+      be[u] = *(const f32x4*)(p.beta + ch[u]);
+    }
+  }
   {
     float m, r;
     gn_fold(p.acc, b, tid >> 3, tid & 7, (double)cpg * (double)p.HW, p.eps, &m, &r);
     if ((tid & 7) == 0) { s_mean[tid >> 3] = m; s_rstd[tid >> 3] = r; }
   }
   __syncthreads();
-  const int64_t total = (int64_t)p.HW * nq;
-  const int64_t base = (int64_t)blockIdx.x * (256 * U) + tid;   // quad index inside this batch row
-  f32x4 v[U]; size_t pix[U]; int ch[U];
-#pragma unroll
-  for (int u = 0; u < U; ++u) {
-    const int64_t idx = base + u * 256;
-    if (idx < total) {
-      pix[u] = (size_t)b * p.HW + (size_t)(idx / nq);
-      ch[u] = (int)(idx % nq) * 4;
-      v[u] = load_cat4(p.x0, p.x1, p.c0, p.c1, pix[u], ch[u]);
-    }
-  }
 #pragma unroll
   for (int u = 0; u < U; ++u) {
     if (base + u * 256 >= total) continue;
     const int c = ch[u];
-    const f32x4 ga = *(const f32x4*)(p.gamma + c);
-    const f32x4 be = *(const f32x4*)(p.beta + c);
-    const int g0 = c / cpg, g1 = (c + 3) / cpg;          // a quad touches at most two groups (cpg >= 2)
+    const int g0 = gn_fast_div(c, magic_cpg), g1 = gn_fast_div(c + 3, magic_cpg);   // a quad touches at most two groups (cpg >= 2)
     const float m0 = s_mean[g0], r0 = s_rstd[g0], m1 = s_mean[g1], r1 = s_rstd[g1];
     const int split = (g0 + 1) * cpg - c;                // first channel offset that belongs to g1
     f32x4 y;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool second = j >= split;
-      float t = (v[u][j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[j] + be[j];
+      float t = (v[u][j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[u][j] + be[u][j];
       if (p.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
       y[j] = t;
     }
@@ -225,10 +238,14 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
     const int64_t quads = (int64_t)p.HW * (C / 4);
     static const int64_t u4_from = getenv("SDMI_GN_APPLY_U4_QUADS") ? atoll(getenv("SDMI_GN_APPLY_U4_QUADS")) : ((int64_t)1 << 20);   // A/B knob
+    const int nq = C / 4;
+    // multiply-shift division needs (quad index + a block's overshoot) * divisor < 2^40
+    const unsigned long long magic_nq = ((quads + 1024) * (int64_t)nq < ((int64_t)1 << 40) && quads + 1024 < ((int64_t)1 << 31)) ? gn_div_magic(nq) : 0ull;
+    const unsigned long long magic_cpg = gn_div_magic(C / 32);           // (c + 3) * cpg < 2^40 always
     if (quads >= u4_from)
-      hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((unsigned)((quads + 1023) / 1024), p.B), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((unsigned)((quads + 1023) / 1024), p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg);
     else
-      hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p);
+      hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg);
   }
   SDMI_HIP_OK(hipGetLastError());
   if (range_check_enabled()) {

@@ -488,6 +488,7 @@ struct Fwd : FwdBase {
       IGemmParams p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
       p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
       attach_gn_targets(p, out);           // ... and those of the GroupNorm(s) that read this block's output
+      attach_f16_copy(p, out);             // ... and the fp16 copy a Downsample / Upsample behind this block wants
       gemm(p);
     }
     scratch.off = mark;
@@ -596,6 +597,7 @@ struct Fwd : FwdBase {
       p.Hout = H * W;                       // (dense: rows per sample)
       p.bias = L.f32[3]; p.residual = x.p; p.ldr = C; p.out_f32 = out.p; p.ldo = C;
       attach_gn_targets(p, out);
+      attach_f16_copy(p, out);
       gemm(p);
     }
     scratch.off = mark;
@@ -613,8 +615,17 @@ struct Fwd : FwdBase {
     const int Hin = x.H, Win = x.W, C = x.C;
     const int Hout = up ? 2 * Hin : (Hin - 1) / 2 + 1, Wout = up ? 2 * Win : (Win - 1) / 2 + 1;
     const size_t mark = scratch.off;
-    f16* x16 = S<f16>((size_t)B * Hin * Win * C);
-    if (!dry && !rc) ok(launch_cast_f16(x.p, x16, nullptr, (int64_t)B * Hin * Win * C, s));
+    // the fp16 operand: stored by the producing GEMM's epilogue when there is one (see FwdBase::attach_f16_copy), else cast here
+    const f16* x16 = nullptr;
+    if (dry) { if (!want_f16_copy(x)) (void)S<f16>((size_t)B * Hin * Win * C); }
+    else {
+      x16 = f16_copy(x);
+      if (!x16) {
+        f16* c = S<f16>((size_t)B * Hin * Win * C);
+        if (!rc) ok(launch_cast_f16(x.p, c, nullptr, (int64_t)B * Hin * Win * C, s));
+        x16 = c;
+      }
+    }
     Act out = make_act(P<float>((size_t)B * Hout * Wout * C), L.cout, Hout, Wout, true);
     IGemmParams p = conv3(x16, C, Hin, Win, Hout, Wout, up ? 1 : 2, up ? 1 : 0, L.w16[0], L.cout);
     p.bias = L.f32[0]; p.out_f32 = out.p; p.ldo = L.cout;

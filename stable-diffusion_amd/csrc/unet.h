@@ -25,7 +25,8 @@ struct Arena {
 
 // an fp32 NHWC activation.  `id` / `stats` serve the GroupNorm-statistics fusion: an activation produced by an igemm
 // epilogue (or its split-K reduce) can have the {sum, sumsq} of its consumers' GroupNorm groups accumulated there.
-struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; int id = -1; bool stats = false; };
+// `can_f16`: the producer is an igemm launch that can also store the fp16 rounding of its output (see want_f16 below).
+struct Act { float* p = nullptr; int C = 0, H = 0, W = 0; int id = -1; bool stats = false; bool can_f16 = false; };
 
 // one GroupNorm that will read an activation: accumulator region index, the activation's first channel inside that
 // GroupNorm's (concatenated) input, channels per group
@@ -33,7 +34,10 @@ struct GnTarget { int gn_idx = 0, cbase = 0, cpg = 0; };
 struct GnPlan {                       // built by the dry pass of a forward, consumed by the real pass
   std::vector<std::vector<GnTarget>> targets;    // per activation id
   std::vector<char> fused;                       // per GroupNorm call: statistics come from the producers' epilogues
-  void clear() { targets.clear(); fused.clear(); }
+  // per activation id: a Downsample / Upsample convolution will read it as an fp16 MFMA operand -- the producing GEMM's
+  // epilogue (or its split-K reduce) stores that copy beside the fp32 output instead of a cast launch in front of the conv
+  std::vector<char> want_f16;
+  void clear() { targets.clear(); fused.clear(); want_f16.clear(); }
 };
 
 // state and helpers shared by the executors (UNet forward, first-stage encode / decode): arenas, GroupNorm accumulator
@@ -62,7 +66,32 @@ struct FwdBase {
     Act a; a.p = ptr; a.C = C; a.H = H; a.W = W; a.id = n_acts++;
     a.stats = by_igemm && plan != nullptr && (H * W) % 32 == 0 && H * W >= 1024 / C + 2 && C % 4 == 0 && C / 32 >= 2;
     if (plan && dry && (int)plan->targets.size() < n_acts) plan->targets.resize(n_acts);
+    if (plan && dry && (int)plan->want_f16.size() < n_acts) plan->want_f16.resize(n_acts, 0);
     return a;
+  }
+  // fp16 copy of activation `a` for a resampling convolution (openaimodel.py:116-118,150-153).  Dry pass: the CONSUMER
+  // (want_f16_copy) records the wish and accounts the bytes; real pass: the PRODUCER's GEMM (attach_f16_copy) allocates the
+  // copy and stores it from its epilogue, the consumer picks it up (f16_copy) -- same rounding of the same fp32 values as
+  // the cast kernel it replaces.  The persist arena never rewinds, so the different allocation order of the two passes
+  // does not change its size.
+  std::vector<f16*> f16_of;
+  void attach_f16_copy(IGemmParams& p, Act& a) {
+    a.can_f16 = plan != nullptr && p.out_f16 == nullptr && p.mode == EPI_PLAIN;
+    if (dry || !a.can_f16 || a.id < 0 || a.id >= (int)plan->want_f16.size() || !plan->want_f16[a.id]) return;
+    f16* c = P<f16>((size_t)B * a.H * a.W * a.C);
+    if ((int)f16_of.size() <= a.id) f16_of.resize(a.id + 1, nullptr);
+    f16_of[a.id] = c;
+    p.out_f16 = c;
+  }
+  bool want_f16_copy(const Act& a) {          // dry pass, consumer side; true: the copy will exist in the real pass
+    if (!dry || !plan || !a.can_f16 || a.id < 0 || a.id >= (int)plan->want_f16.size()) return false;
+    if (const char* e = getenv("SDMI_F16_COPY")) { if (atoi(e) == 0) return false; }   // A/B knob: 0 = cast launches (bit-identical)
+    plan->want_f16[a.id] = 1;
+    (void)P<f16>((size_t)B * a.H * a.W * a.C);
+    return true;
+  }
+  const f16* f16_copy(const Act& a) const {   // real pass, consumer side
+    return (!dry && a.id >= 0 && a.id < (int)f16_of.size()) ? f16_of[a.id] : nullptr;
   }
   // attach the statistics targets of activation `a` (all GroupNorms that will read it and rely on fused statistics)
   void attach_gn_targets(IGemmParams& p, const Act& a) {

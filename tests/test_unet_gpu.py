@@ -139,8 +139,9 @@ def test_batch_rows_are_independent(cfg_name, B, h, w):
 
 @pytest.mark.parametrize('cfg_name,B,h,w', [('tiny', 2, 16, 16), ('small40', 2, 16, 16), ('sdv1', 2, 32, 32), ('sdv1', 2, 64, 64)])
 def test_16_byte_epilogues_are_bit_identical(cfg_name, B, h, w, monkeypatch):
-    """The GEMM epilogues that turn the accumulators through LDS and store 16 bytes per lane (igemm.hip, default) perform the
-    same arithmetic value by value as the dword / short epilogues (SDMI_EPI_VEC=0): eps must not change by one bit."""
+    """Value-neutral launch-level optimisations against the code they replaced, selected by their A/B knobs: the GEMM
+    epilogues that turn the accumulators through LDS and store 16 bytes per lane (SDMI_EPI_VEC), the fp16 resampling operand
+    from the producer's epilogue (SDMI_F16_COPY), the LDS-staged small_linear (SDMI_SMALL_LDS): eps must not change by one bit."""
     cfg = CFGS[cfg_name]
     m, sd = _model(cfg_name, 0)
     x, t, ctx = make_inputs(cfg, B, h, w, seed=11)
@@ -150,10 +151,19 @@ def test_16_byte_epilogues_are_bit_identical(cfg_name, B, h, w, monkeypatch):
     e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
     monkeypatch.setenv('SDMI_EPI_VEC', '1')
     e2 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    # the fp16 operand of the Downsample / Upsample convs stored by the producing GEMM's epilogue vs a cast launch
+    monkeypatch.setenv('SDMI_F16_COPY', '0')
+    e3 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_F16_COPY', '1')
+    # LDS-staged small_linear (time embedding MLPs) vs the one-load-at-a-time kernel
+    monkeypatch.setenv('SDMI_SMALL_LDS', '0')
+    e4 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
     torch.cuda.synchronize()
     assert torch.isfinite(e1).all()
     assert torch.equal(e1, e2)
     assert torch.equal(e1, e0), float((e1 - e0).abs().max())
+    assert torch.equal(e1, e3), float((e1 - e3).abs().max())
+    assert torch.equal(e1, e4), float((e1 - e4).abs().max())
 
 
 def test_more_than_8_rows_is_chunked():
