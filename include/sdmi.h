@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 7
+#define SDMI_ABI_VERSION 8
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -72,6 +72,18 @@ int64_t sdmi_unet_workspace_bytes(sdmi_unet* h, int B, int H, int W, int Lctx);
  * compute them once per prompt.  ctx: fp32 [B, Lctx, context_dim]. */
 int sdmi_unet_cache_context(sdmi_unet* h, const float* ctx, int B, int Lctx, void* workspace, int64_t workspace_bytes,
                             void* stream);
+
+/* The timestep path of UNetModel.forward -- timestep_embedding -> time_embed (openaimodel.py:723-724) -> every ResBlock's
+ * emb_layers (openaimodel.py:218-224, 22 Linear layers = a 20160 x 1280 fp32 matrix for SD v1) -- depends on the timestep
+ * only.  A sampler knows its timesteps in advance (plms.py:121-128, ddim.py:129-134): `cache_timesteps` computes the rows for
+ * a list of INTEGER timesteps in one batch (the weights are read once per 8 timesteps instead of once per UNet call; same
+ * kernels, rows are independent: bit-identical values), on `stream`, replacing any earlier table.  `hint_timestep(t)`
+ * tells the NEXT sdmi_unet_forward that every row of its timestep tensor equals t: if t is in the table the call takes
+ * the cached rows and launches nothing for the timestep path; otherwise (or without a hint) it computes them from its
+ * timestep tensor as before.  The hint is the caller's assertion -- it is not checked against the device tensor -- and is
+ * consumed by that one call.  t_host: host memory.  Setting weights drops the table. */
+int sdmi_unet_cache_timesteps(sdmi_unet* h, const int64_t* t_host, int n, void* stream);
+int sdmi_unet_hint_timestep(sdmi_unet* h, int64_t t);
 
 /* UNetModel.forward(x, timesteps, context) openaimodel.py:710-742, reached through
  * LatentDiffusion.apply_model ddpm.py:891-900,986-992 and DiffusionWrapper.forward ddpm.py:1402-1410.

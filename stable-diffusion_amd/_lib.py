@@ -59,6 +59,8 @@ _SIGS = {
     'sdmi_unet_import_packed': (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_unet_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int]),
     'sdmi_unet_cache_context': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_unet_cache_timesteps': (C.c_int, [c_ptr, C.POINTER(C.c_int64), C.c_int, c_ptr]),
+    'sdmi_unet_hint_timestep': (C.c_int, [c_ptr, C.c_int64]),
     'sdmi_unet_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_ptr, C.c_int64, c_ptr]),
     'sdmi_sampler_step': (C.c_int, [c_ptr, C.c_int, C.c_float, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr, C.c_float,
@@ -138,7 +140,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 7:
+        if lib.sdmi_abi_version() != 8:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

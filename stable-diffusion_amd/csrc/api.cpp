@@ -92,6 +92,14 @@ int sdmi_unet_cache_context(sdmi_unet* h, const float* ctx, int B, int Lctx, voi
   return h->impl.run(nullptr, nullptr, nullptr, ctx, nullptr, B, down, down, Lctx, workspace, workspace_bytes,
                      (hipStream_t)stream, false, true, nullptr);
 }
+int sdmi_unet_cache_timesteps(sdmi_unet* h, const int64_t* t_host, int n, void* stream) {
+  SDMI_CHECK(h, "null argument");
+  return h->impl.cache_timesteps(t_host, n, (hipStream_t)stream);
+}
+int sdmi_unet_hint_timestep(sdmi_unet* h, int64_t t) {
+  SDMI_CHECK(h, "null argument");
+  return h->impl.hint_timestep(t);
+}
 int sdmi_unet_forward(sdmi_unet* h, const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx,
                       float* eps_out, int B, int H, int W, int Lctx, void* workspace, int64_t workspace_bytes, void* stream) {
   SDMI_CHECK(h && x && eps_out, "null argument");

@@ -225,6 +225,8 @@ UNet::~UNet() {
     (void)hipStreamDestroy(side_);
   }
   for (void* p : owned_) (void)hipFree(p);
+  if (emb_tab_) (void)hipFree(emb_tab_);
+  if (emb_tab_tdev_) (void)hipFree(emb_tab_tdev_);
   auto drop_ctx = [](Layer& L) {            // cross-attention K / V^T caches (ensure_ctx_cache)
     for (auto& T : L.tb) {
       if (T.ck) (void)hipFree(T.ck);
@@ -330,6 +332,7 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
   s.set = true;
   finalized_ = false;
   ctx_valid_ = false;      // cached cross-attention K/V were computed with the previous to_k / to_v weights
+  drop_timestep_table();   // ... and the timestep table with the previous time_embed / emb_layers weights
   return 0;
 }
 
@@ -414,6 +417,7 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
   SDMI_HIP_OK(hipStreamSynchronize(stream));
   for (auto& s : slots_) s.set = true;
   ctx_valid_ = false;
+  drop_timestep_table();
   return finalize();
 }
 
@@ -422,7 +426,8 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
 // ------------------------------------------------------------------------------------------------------
 struct Fwd : FwdBase {
   UNet* u; int Lctx;
-  float* emb_all = nullptr;     // [B][emb_total]
+  float* emb_all = nullptr;     // [B][emb_total] (emb_ld = emb_total), or one row of the timestep table shared by every sample (emb_ld = 0)
+  int emb_ld = 0;
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
 
   void gn_stats_only(const Act& x0, const Act* x1, float eps, f16* raw, f16* raw_lo, const float* gamma, const float* beta) {
@@ -454,7 +459,7 @@ struct Fwd : FwdBase {
       Conv3GnParams c;
       c.x0 = x0.p; c.c0 = x0.C; if (x1) { c.x1 = x1->p; c.c1 = x1->C; }
       c.acc = last_gn_acc(); c.eps = 1e-5f; c.gamma = L.f32[0]; c.beta = L.f32[1]; c.B = B; c.H = H; c.W = W;
-      c.w = L.w16[0]; c.N = Cout; c.bias = L.f32[2]; c.rowvec = emb_all + L.emb_off; c.ld_rowvec = u->emb_total_;
+      c.w = L.w16[0]; c.N = Cout; c.bias = L.f32[2]; c.rowvec = emb_all + L.emb_off; c.ld_rowvec = emb_ld;
       c.out = h; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
       if (!dry && !rc) ok(launch_conv3gn(c, s));
     } else {
@@ -462,7 +467,7 @@ struct Fwd : FwdBase {
       groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
       if (Cin != Cout) fork_side();
       IGemmParams p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
-      p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = u->emb_total_;
+      p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = emb_ld;
       p.out_f32 = h; p.ldo = Cout;
       attach_gn_targets(p, hact);          // statistics of out_layers' GroupNorm come out of this epilogue
       gemm(p);
@@ -666,6 +671,51 @@ int UNet::ensure_ctx_cache(int B, int Lctx) {
   return 0;
 }
 
+int UNet::cache_timesteps(const int64_t* t_host, int n, hipStream_t stream) {
+  SDMI_CHECK(finalized_, "sdmi_unet_finalize() has not succeeded yet");
+  SDMI_CHECK(n >= 0 && n <= 4096 && (n == 0 || t_host != nullptr), "bad timestep list");
+  drop_timestep_table();
+  if (n == 0) return 0;
+  const int mc = cfg_.model_channels;
+  const size_t row = (size_t)emb_total_, tmp = (size_t)8 * (mc + 2 * (size_t)te_);
+  const size_t need = (size_t)n * row + tmp;
+  if (need > emb_tab_floats_) {              // (grow-only; called once per sampling run, not per UNet call)
+    if (emb_tab_) (void)hipFree(emb_tab_);
+    emb_tab_ = nullptr; emb_tab_floats_ = 0;
+    SDMI_HIP_OK(hipMalloc((void**)&emb_tab_, need * sizeof(float)));
+    emb_tab_floats_ = need;
+  }
+  if ((size_t)n > emb_tab_tcap_) {
+    if (emb_tab_tdev_) (void)hipFree(emb_tab_tdev_);
+    emb_tab_tdev_ = nullptr; emb_tab_tcap_ = 0;
+    SDMI_HIP_OK(hipMalloc((void**)&emb_tab_tdev_, (size_t)n * sizeof(int64_t)));
+    emb_tab_tcap_ = (size_t)n;
+  }
+  std::vector<int64_t> host(t_host, t_host + n);      // (the copy below reads a buffer this object owns, not the caller's)
+  emb_tab_src_.swap(host);
+  SDMI_HIP_OK(hipMemcpyAsync(emb_tab_tdev_, emb_tab_src_.data(), (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice, stream));
+  float* temb = emb_tab_ + (size_t)n * row;
+  float* e1 = temb + (size_t)8 * mc;
+  float* emb = e1 + (size_t)8 * te_;
+  for (int i0 = 0; i0 < n; i0 += 8) {        // the same launches as a forward's timestep path, 8 timesteps as the batch rows
+    const int nb = std::min(8, n - i0);
+    int r = launch_timestep_embedding(emb_tab_tdev_ + i0, nullptr, temb, nb, mc, stream);
+    if (!r) r = launch_small_linear(temb, mc, te_w0_, te_b0_, e1, te_, nb, te_, mc, 0, stream);
+    if (!r) r = launch_small_linear(e1, te_, te_w2_, te_b2_, emb, te_, nb, te_, te_, 1, stream);
+    if (!r) r = launch_small_linear(emb, te_, emb_w_, emb_b_, emb_tab_ + (size_t)i0 * row, emb_total_, nb, emb_total_, te_, 1, stream);
+    if (r) return r;
+  }
+  emb_tab_t_ = emb_tab_src_;
+  return 0;
+}
+
+int UNet::hint_timestep(int64_t t) {
+  emb_hint_row_ = -1;
+  for (size_t i = 0; i < emb_tab_t_.size(); ++i)
+    if (emb_tab_t_[i] == t) { emb_hint_row_ = (int)i; break; }
+  return 0;
+}
+
 int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx, float* eps_out, int B, int H,
               int W, int Lctx, void* workspace, int64_t ws_bytes, hipStream_t stream, bool dry, bool ctx_only,
               int64_t* bytes_needed) {
@@ -725,7 +775,12 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       float* e1 = f.P<float>((size_t)B * te_);
       float* emb = f.P<float>((size_t)B * te_);
       f.emb_all = f.P<float>((size_t)B * emb_total_);
-      if (!d) {
+      f.emb_ld = emb_total_;
+      if (!d && emb_hint_row_ >= 0 && emb_hint_row_ < (int)emb_tab_t_.size()) {
+        // every row has the hinted timestep and its emb_layers outputs are in the table: one shared row, nothing to launch
+        f.emb_all = emb_tab_ + (size_t)emb_hint_row_ * emb_total_;
+        f.emb_ld = 0;
+      } else if (!d) {
         int r = launch_timestep_embedding(t_i64, t_f32, temb, B, mc, stream);
         if (!r) r = launch_small_linear(temb, mc, te_w0_, te_b0_, e1, te_, B, te_, mc, 0, stream);
         if (!r) r = launch_small_linear(e1, te_, te_w2_, te_b2_, emb, te_, B, te_, te_, 1, stream);
@@ -762,6 +817,7 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     else {
       SDMI_CHECK(!f.persist.overflow && !f.scratch.overflow, "internal: arena overflow");
       if (have_ctx) ctx_valid_ = true;
+      if (!ctx_only) emb_hint_row_ = -1;       // the hint was for this call
     }
   }
   if (bytes_needed) *bytes_needed = persist_bytes + scratch_bytes;

@@ -265,6 +265,11 @@ class UNet {
   int run(const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx, float* eps_out, int B, int H, int W,
           int Lctx, void* workspace, int64_t ws_bytes, hipStream_t stream, bool dry, bool ctx_only, int64_t* bytes_needed);
 
+  // emb_all rows of a list of integer timesteps, computed in one batch (include/sdmi.h: sdmi_unet_cache_timesteps);
+  // hint: the next run()'s rows all have timestep t
+  int cache_timesteps(const int64_t* t_host, int n, hipStream_t stream);
+  int hint_timestep(int64_t t);
+
   const std::vector<WeightSlot>& slots() const { return slots_; }
 
   sdmi_unet_cfg cfg_{};
@@ -300,6 +305,13 @@ class UNet {
   float *out_gamma_ = nullptr, *out_beta_ = nullptr, *out_w_ = nullptr, *out_b_ = nullptr;
   bool finalized_ = false;
   int ctx_B_ = 0, ctx_L_ = 0; bool ctx_valid_ = false;
+  // timestep table: [n][emb_total] fp32 rows + scratch for one chunk of 8 timesteps (grow-only device buffer)
+  float* emb_tab_ = nullptr; size_t emb_tab_floats_ = 0;
+  int64_t* emb_tab_tdev_ = nullptr; size_t emb_tab_tcap_ = 0;
+  std::vector<int64_t> emb_tab_t_;        // timesteps of the table rows (empty: no table)
+  std::vector<int64_t> emb_tab_src_;      // host source of the last upload (kept alive for the asynchronous copy)
+  int emb_hint_row_ = -1;
+  void drop_timestep_table() { emb_tab_t_.clear(); emb_hint_row_ = -1; }
 };
 
 }  // namespace sdmi

@@ -118,6 +118,10 @@ class _SamplerBase(object):
         if cfg:
             x_in[b:].copy_(img)
         t_in = torch.full((x_in.shape[0],), t_val, device=x_in.device, dtype=t_dtype)
+        if t_dtype == torch.long:
+            unet = self._hip_unet()
+            if unet is not None:
+                unet.hint_timestep(int(t_val))      # every row of t_in is this int: rows of the timestep table, if cached
         out = self.model.apply_model(x_in, t_in, c_in)
         return out.float().contiguous()
 
@@ -161,6 +165,7 @@ class PLMSSamplerHIP(_SamplerBase):
         unet = self._hip_unet()
         if unet is not None:
             unet.pin_context(c_in)
+            unet.cache_timesteps([t for p in plan for t in (p[2], p[3]) if t is not None])
         try:
             img = self._plms_loop(plan, total_steps, device, b, img, cfg, c_in, x_in, scale, mask, x0, callback,
                                   img_callback, log_every_t, intermediates, old_eps)
@@ -236,6 +241,7 @@ class DDIMSamplerHIP(_SamplerBase):
         unet = self._hip_unet()
         if unet is not None:
             unet.pin_context(c_in)
+            unet.cache_timesteps([int(t) for t in time_range])
         try:
             img = self._ddim_loop(time_range, total_steps, device, b, img, cfg, c_in, x_in, scale, mask, x0, callback,
                                   img_callback, log_every_t, temperature, noise_dropout, intermediates, desc)

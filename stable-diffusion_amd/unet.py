@@ -13,6 +13,7 @@ libsdmi.so (hand-written gfx950 kernels); this class only owns the parameters, p
 library on first use and hands raw device pointers across the C ABI.
 """
 import ctypes as C
+import os
 
 import torch
 import torch.nn as nn
@@ -240,6 +241,25 @@ class UNetModelHIP(nn.Module):
         self._pinned = None
         self._pinned_ctx = None
 
+    # ---- timestep table (used by the HIP samplers) ----------------------------------------------------------------
+    def cache_timesteps(self, timesteps):
+        """Compute the timestep path -- timestep_embedding -> time_embed -> the 22 emb_layers (openaimodel.py:723-724,
+        218-224), which depends on the timestep only -- for a list of INTEGER timesteps in one batch
+        (sdmi_unet_cache_timesteps).  A forward() announced by hint_timestep(t) then takes its rows from the table instead
+        of re-reading the 103 MB of fp32 emb_layers weights; the values are bit-identical.  SDMI_T_TABLE=0 disables it."""
+        if os.environ.get('SDMI_T_TABLE', '1') == '0':
+            return
+        if self._needs_pack():
+            self.pack()
+        ts = sorted({int(t) for t in timesteps})
+        arr = (C.c_int64 * len(ts))(*ts)
+        _lib.check(self._handle.lib.sdmi_unet_cache_timesteps(self._handle.h, arr, len(ts), _lib.stream_ptr()))
+
+    def hint_timestep(self, t):
+        """Every row of the NEXT forward()'s integer `timesteps` tensor equals t (the samplers build that tensor from this
+        very int, plms.py:137, ddim.py:148): take the cached rows if cache_timesteps() covered t."""
+        self._t_hint = int(t)
+
     def _pinned_matches(self, context):
         ref, ver, saved = self._pinned_ctx
         if context is ref and context._version == ver:
@@ -261,17 +281,18 @@ class UNetModelHIP(nn.Module):
         B, Cin, H, W = x.shape
         assert Cin == self.in_channels
         assert timesteps.shape == (B,)
+        t_hint, self._t_hint = getattr(self, '_t_hint', None), None          # (one-shot: consumed by this call)
         assert context.dim() == 3 and context.shape[0] == B and context.shape[2] == self.context_dim
         if B > self.MAX_ROWS:
             # e.g. `txt2img.py --n_samples 5` = CFG batch 10 (scripts/txt2img.py:110-114): the reference has no
             # cross-sample op (GroupNorm and attention are per sample), so the batch is evaluated in chunks of <= 8 rows
             outs = [self._forward_rows(x[i:i + self.MAX_ROWS], timesteps[i:i + self.MAX_ROWS],
-                                       context[i:i + self.MAX_ROWS], allow_reuse=False)
+                                       context[i:i + self.MAX_ROWS], allow_reuse=False, t_hint=t_hint)
                     for i in range(0, B, self.MAX_ROWS)]
             return torch.cat(outs, dim=0)
-        return self._forward_rows(x, timesteps, context, allow_reuse=True)
+        return self._forward_rows(x, timesteps, context, allow_reuse=True, t_hint=t_hint)
 
-    def _forward_rows(self, x, timesteps, context, allow_reuse):
+    def _forward_rows(self, x, timesteps, context, allow_reuse, t_hint=None):
         B, Cin, H, W = x.shape
         x32 = x.detach().float().contiguous()
         if timesteps.dtype in (torch.int64, torch.int32, torch.int16, torch.uint8):
@@ -292,6 +313,8 @@ class UNetModelHIP(nn.Module):
         if not reuse:
             ctx32 = context.detach().float().contiguous()
         out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
+        if t_hint is not None and t_i64 is not None:
+            _lib.check(self._handle.lib.sdmi_unet_hint_timestep(self._handle.h, int(t_hint)))
         _lib.check(self._handle.lib.sdmi_unet_forward(
             self._handle.h, x32.data_ptr(), _lib.ptr(t_i64), _lib.ptr(t_f32), _lib.ptr(ctx32), out.data_ptr(),
             B, H, W, L, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))

@@ -166,6 +166,38 @@ def test_16_byte_epilogues_are_bit_identical(cfg_name, B, h, w, monkeypatch):
     assert torch.equal(e1, e4), float((e1 - e4).abs().max())
 
 
+@pytest.mark.parametrize('cfg_name,B,h,w', [('tiny', 2, 16, 16), ('sdv1', 2, 16, 16), ('tiny', 10, 8, 8)])
+def test_timestep_table_is_bit_identical(cfg_name, B, h, w):
+    """sdmi_unet_cache_timesteps / hint_timestep (the samplers' fast path for openaimodel.py:723-724 + the emb_layers): a
+    hinted forward takes its timestep rows from the table -- same kernels, batched over the timesteps -- and must return the
+    same bits as an unhinted one; a timestep outside the table, a consumed hint and re-set weights fall back to the tensor."""
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, 0)
+    x, _, ctx = make_inputs(cfg, B, h, w, seed=12)
+    x, ctx = x.cuda(), ctx.cuda()
+    m.cache_timesteps([981, 961, 481, 1, 0] + list(range(100, 120)))        # 25 timesteps: four chunks of <= 8
+    for t in (481, 1, 0, 981, 119, 7):                                      # 7 is not in the table
+        tt = torch.full((B,), t, dtype=torch.long, device='cuda')
+        plain = m(x, tt, context=ctx).clone()
+        m.hint_timestep(t)
+        hinted = m(x, tt, context=ctx).clone()
+        again = m(x, tt, context=ctx).clone()                               # the hint was consumed: computed from the tensor
+        assert torch.equal(plain, hinted), (t, float((plain - hinted).abs().max()))
+        assert torch.equal(plain, again)
+    # a hint followed by a DIFFERENT timestep tensor would be the caller's error; an unhinted call after a hinted one is not
+    m.hint_timestep(481)
+    m(x, torch.full((B,), 481, dtype=torch.long, device='cuda'), context=ctx)
+    t2 = torch.full((B,), 961, dtype=torch.long, device='cuda')
+    e_a = m(x, t2, context=ctx).clone()
+    m.hint_timestep(961)
+    e_b = m(x, t2, context=ctx).clone()
+    assert torch.equal(e_a, e_b)
+    assert not torch.equal(e_a, plain)
+    m.cache_timesteps([])                                                   # dropping the table: hints find nothing
+    m.hint_timestep(961)
+    assert torch.equal(m(x, t2, context=ctx), e_a)
+
+
 def test_more_than_8_rows_is_chunked():
     """`txt2img.py --n_samples 5` is a CFG batch of 10: the library takes <= 8 rows per call, UNetModelHIP.forward splits the
     batch (rows are independent) -- bit-identical to calling the chunks by hand, with and without a pinned context."""
