@@ -324,3 +324,84 @@ def test_committed_tuning_table_is_well_formed():
         key = tuple(r[:8])
         assert key not in seen, key
         seen.add(key)
+
+
+def test_package_modules_reference_no_undefined_module_names():
+    """Every `name.attr` in the host package resolves to an import, a local definition or a builtin (a missing `import os` in a
+    GPU-only code path is invisible to the CPU suite otherwise)."""
+    import ast
+    import builtins
+    pkg = os.path.join(ROOT, 'stable-diffusion_amd')
+    for fn in sorted(os.listdir(pkg)):
+        if not fn.endswith('.py'):
+            continue
+        tree = ast.parse(open(os.path.join(pkg, fn)).read())
+        known = set(dir(builtins))
+        for n in ast.walk(tree):
+            if isinstance(n, ast.Import):
+                known |= {(a.asname or a.name).split('.')[0] for a in n.names}
+            elif isinstance(n, ast.ImportFrom):
+                known |= {a.asname or a.name for a in n.names}
+            elif isinstance(n, (ast.FunctionDef, ast.ClassDef, ast.AsyncFunctionDef)):
+                known.add(n.name)
+            elif isinstance(n, ast.Name) and isinstance(n.ctx, ast.Store):
+                known.add(n.id)
+            elif isinstance(n, ast.arguments):
+                known |= {a.arg for a in n.args + n.kwonlyargs + n.posonlyargs}
+                known |= {a.arg for a in (n.vararg, n.kwarg) if a is not None}
+            elif isinstance(n, ast.ExceptHandler) and n.name:
+                known.add(n.name)
+        used = {n.value.id for n in ast.walk(tree) if isinstance(n, ast.Attribute) and isinstance(n.value, ast.Name)}
+        assert used <= known, (fn, sorted(used - known))
+
+
+def test_timestep_table_host_plumbing(monkeypatch):
+    """UNetModelHIP.cache_timesteps / hint_timestep / forward as far as the C calls (recorded by a stand-in library): the list
+    is deduplicated and sorted, the hint is one-shot, reaches every chunk of a > 8-row batch, and only integer timesteps."""
+    from stable_diffusion_amd import _lib
+    from stable_diffusion_amd.unet import UNetModelHIP
+    calls = []
+
+    class FakeLib:
+        def sdmi_unet_cache_timesteps(self, h, arr, n, s):
+            calls.append(('cache', list(arr)[:n])); return 0
+
+        def sdmi_unet_hint_timestep(self, h, t):
+            calls.append(('hint', t)); return 0
+
+        def sdmi_unet_forward(self, *a):
+            calls.append(('forward', a[6])); return 0          # a[6] = B
+
+        def sdmi_unet_workspace_bytes(self, h, B, H, W, L):
+            return 256
+
+    class Handle:
+        lib = FakeLib(); h = None
+
+    class FakeTensor(torch.Tensor):
+        pass
+
+    m = UNetModelHIP.__new__(UNetModelHIP)
+    torch.nn.Module.__init__(m)
+    m._handle = Handle(); m._needs_pack = lambda: False
+    m.in_channels, m.out_channels, m.context_dim = 4, 4, 8
+    m._ws = None; m._pinned = None; m._pinned_ctx = None; m._ctx_ref = None; m._ctx_ver = None; m._ctx_shape = None
+    monkeypatch.setattr(_lib, 'stream_ptr', lambda: None)
+    m.cache_timesteps([981, 5, 5, 3])
+    assert calls == [('cache', [3, 5, 981])]
+    monkeypatch.setenv('SDMI_T_TABLE', '0')
+    m.cache_timesteps([1, 2])
+    assert len(calls) == 1
+    # forward(): CPU tensors are refused before any C call, so drive _forward_rows' hint logic through a patched is_cuda check
+    x = torch.zeros(10, 4, 8, 8); ctx = torch.zeros(10, 77, 8)
+    monkeypatch.setattr(torch.Tensor, 'is_cuda', property(lambda self: True))
+    m.hint_timestep(5)
+    m.forward(x, torch.full((10,), 5, dtype=torch.long), context=ctx)
+    assert [c for c in calls[1:]] == [('hint', 5), ('forward', 8), ('hint', 5), ('forward', 2)]
+    del calls[:]
+    m.forward(x[:2], torch.full((2,), 5, dtype=torch.long), context=ctx[:2])           # the hint was consumed
+    assert calls == [('forward', 2)]
+    del calls[:]
+    m.hint_timestep(5)
+    m.forward(x[:2], torch.full((2,), 5.0), context=ctx[:2])                           # float timesteps (DPM-Solver): no hint
+    assert calls == [('forward', 2)]
