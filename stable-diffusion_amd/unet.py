@@ -282,6 +282,10 @@ class UNetModelHIP(nn.Module):
         assert Cin == self.in_channels
         assert timesteps.shape == (B,)
         t_hint, self._t_hint = getattr(self, '_t_hint', None), None          # (one-shot: consumed by this call)
+        if t_hint is not None and os.environ.get('SDMI_CHECK_T_HINT') == '1':
+            # debug: the hint is the caller's assertion about a device tensor; this check costs a device round trip
+            if not bool((timesteps == t_hint).all()):
+                raise RuntimeError(f'hint_timestep({t_hint}) does not describe the timesteps tensor {timesteps.tolist()}')
         assert context.dim() == 3 and context.shape[0] == B and context.shape[2] == self.context_dim
         if B > self.MAX_ROWS:
             # e.g. `txt2img.py --n_samples 5` = CFG batch 10 (scripts/txt2img.py:110-114): the reference has no

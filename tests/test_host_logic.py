@@ -405,3 +405,7 @@ def test_timestep_table_host_plumbing(monkeypatch):
     m.hint_timestep(5)
     m.forward(x[:2], torch.full((2,), 5.0), context=ctx[:2])                           # float timesteps (DPM-Solver): no hint
     assert calls == [('forward', 2)]
+    monkeypatch.setenv('SDMI_CHECK_T_HINT', '1')                                       # debug: a wrong hint is an error
+    m.hint_timestep(7)
+    with pytest.raises(RuntimeError, match='hint_timestep'):
+        m.forward(x[:2], torch.full((2,), 5, dtype=torch.long), context=ctx[:2])
