@@ -1149,6 +1149,11 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
     const int m = row0 + r;
     if (!ncol || m >= p.M) continue;
     const float* src = p.splitk_ws + (size_t)m * p.N + n;
+    // every load of the row is requested before the first wait: the row vector and the residual used to be fetched
+    // behind the partial sums, one dependent round trip each (three per row instead of one)
+    f32x4 rvv = {0.f, 0.f, 0.f, 0.f}, resv = {0.f, 0.f, 0.f, 0.f};
+    if (p.rowvec) rvv = *(const f32x4*)(p.rowvec + (size_t)(m / HW) * p.ld_rowvec + n);
+    if (p.residual) resv = *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
     f32x4 part[16];
 #pragma unroll
     for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0, 0, 0, 0};
@@ -1156,8 +1161,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
 #pragma unroll
     for (int s = 1; s < 16; ++s) v += part[s];       // fixed order; absent splits add +0
     v += biasv;
-    if (p.rowvec) v += *(const f32x4*)(p.rowvec + (size_t)(m / HW) * p.ld_rowvec + n);
-    if (p.residual) v += *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+    if (p.rowvec) v += rvv;
+    if (p.residual) v += resv;
     if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
     if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
     if (p.out_lo) {
