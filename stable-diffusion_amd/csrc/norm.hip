@@ -261,7 +261,14 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, f16*
   SDMI_CHECK(C % 4 == 0 && C <= 2560, "LayerNorm: C must be a multiple of 4 and <= 2560");
   dim3 grid(cdiv(M, 4)), block(256);
   ProfScope ps("layernorm", 0.0, (double)M * C * 6.0, stream);
-  if (C <= 1280) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  // MAXQ = quads per lane, instantiated per width class: the 5-slot kernel needs 108 VGPRs (4 waves per SIMD) whatever C is,
+  // the 2- and 3-slot ones of C <= 512 / 768 (the 64x64 and 32x32 levels: 320 / 640 channels) keep twice the rows in flight.
+  // Same per-lane order of the same terms: bit-identical.  SDMI_LN_SLOTS=0 = always the 5-slot kernel (A/B).
+  const char* e_slots = getenv("SDMI_LN_SLOTS");
+  const bool narrow = !(e_slots && atoi(e_slots) == 0);
+  if (narrow && C <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  else if (narrow && C <= 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  else if (C <= 1280) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
   else hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
   SDMI_HIP_OK(hipGetLastError());
   return 0;

@@ -488,16 +488,20 @@ def test_groupnorm(c0, c1, HW, silu, eps):
     assert K.report('groupnorm raw hi+lo', o['raw'].float() + o['raw_lo'].float(), x, 4e-6) < 4e-6
 
 
-@pytest.mark.parametrize('M,C', [(8192, 320), (512, 1280), (7, 64), (100, 640)])
-def test_layernorm(M, C):
+@pytest.mark.parametrize('M,C', [(8192, 320), (512, 1280), (7, 64), (100, 640), (2048, 640), (33, 512), (5, 768), (9, 772)])
+def test_layernorm(M, C, monkeypatch):
     g = _g(M + C)
     x = torch.randn(M, C, generator=g) * 2 + 0.5
     gamma = 1 + 0.1 * torch.randn(C, generator=g)
     beta = 0.1 * torch.randn(C, generator=g)
     ref = F.layer_norm(x, (C,), gamma, beta, 1e-5)
-    out = K.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV))
+    monkeypatch.setenv('SDMI_LN_SLOTS', '1')
+    out = K.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV)).clone()
+    monkeypatch.setenv('SDMI_LN_SLOTS', '0')         # the 5-slot instantiation for every width (the only one before)
+    out5 = K.layernorm(x.to(DEV), gamma.to(DEV), beta.to(DEV)).clone()
     torch.cuda.synchronize()
     assert K.report('layernorm', out, ref, 4e-3) < 4e-3
+    assert torch.equal(out, out5)
 
 
 def test_time_embedding_path():

@@ -158,12 +158,17 @@ def test_16_byte_epilogues_are_bit_identical(cfg_name, B, h, w, monkeypatch):
     # LDS-staged small_linear (time embedding MLPs) vs the one-load-at-a-time kernel
     monkeypatch.setenv('SDMI_SMALL_LDS', '0')
     e4 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_SMALL_LDS', '1')
+    # LayerNorm instantiated per width class (2 / 3 quads per lane for 320 / 640 channels) vs the 5-slot kernel
+    monkeypatch.setenv('SDMI_LN_SLOTS', '0')
+    e5 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
     torch.cuda.synchronize()
     assert torch.isfinite(e1).all()
     assert torch.equal(e1, e2)
     assert torch.equal(e1, e0), float((e1 - e0).abs().max())
     assert torch.equal(e1, e3), float((e1 - e3).abs().max())
     assert torch.equal(e1, e4), float((e1 - e4).abs().max())
+    assert torch.equal(e1, e5), float((e1 - e5).abs().max())
 
 
 @pytest.mark.parametrize('cfg_name,B,h,w', [('tiny', 2, 16, 16), ('sdv1', 2, 16, 16), ('tiny', 10, 8, 8)])
