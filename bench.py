@@ -308,7 +308,7 @@ def timed_steps(step_fn, steps, warmup, world, rank, device):
     def sync():
         if device.type == 'cuda':
             torch.cuda.synchronize()
-        if world > 1:
+        if torch.distributed.is_available() and torch.distributed.is_initialized():     # (also a launched world of size 1)
             torch.distributed.barrier()
         if device.type == 'cuda':
             torch.cuda.synchronize()
@@ -405,6 +405,11 @@ def main():
                                    ('(libsdmi AutoencoderKLHIP)' if args.vae == 'hip' else '(PyTorch-ROCm fp16 autocast)'),
                        'global_batch': world, 'parallelism': f'dp{world} (one prompt per GPU, latents all_gather)'},
         }
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # (a process group exists whenever a launcher exported RANK / WORLD_SIZE, also at world size 1)
+            out['collective'] = {'backend': torch.distributed.get_backend(), 'world_size': torch.distributed.get_world_size(),
+                                 'ops_per_step': 'one all_gather of the finished latents (64 KiB per image)',
+                                 'timing': 'all_reduce(MAX) of the timed region over the ranks'}
         if world == 1:
             ms = unet_latency_ms(unet, device, H=LAT, W=LAT)
             out['unet_ms_per_call'] = ms
@@ -419,10 +424,14 @@ def main():
                 fam = [r for r in table if r['name'].startswith(('igemm', 'conv3halo'))]
                 dom = {'name': 'igemm_kernel / conv3halo_kernel (one GEMM core + epilogue, all tile instantiations)',
                        'launches': sum(r['launches'] for r in fam), 'ms': sum(r['ms'] for r in fam),
-                       'flops': sum(r['flops'] for r in fam), 'bytes': sum(r['bytes'] for r in fam)}
+                       'flops': sum(r['flops'] for r in fam), 'flops_exec': sum(r.get('flops_exec', r['flops']) for r in fam),
+                       'bytes': sum(r['bytes'] for r in fam)}
                 top = fam[0]
                 mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'conv3halo', 'attn'))]
+                # `flops` are ALGORITHMIC (2 x MACs of the reference's convs / linears); the 3-pass split-fp16
+                # 1x1 convs execute 3x theirs, which only `achieved_executed` / `frac_executed` count
                 ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
+                ach_exec = dom['flops_exec'] / (dom['ms'] * 1e-3) / 1e12
                 cls = lambda r: {'name': r['name'], 'launches': r['launches'], 'ms': round(r['ms'], 4),
                                  'tflops': round(r['flops'] / (r['ms'] * 1e-3) / 1e12, 1) if r['flops'] else None,
                                  'gbs': round(r['bytes'] / (r['ms'] * 1e-3) / 1e9, 1)}
@@ -430,6 +439,8 @@ def main():
                     'bound': 'mfma', 'kernel': dom['name'], 'launches_per_unet_call': dom['launches'],
                     'avg_launch_ms': dom['ms'] / dom['launches'],
                     'achieved': ach, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_TFLOPS,
+                    'achieved_executed': ach_exec, 'frac_executed': ach_exec / MFMA_PEAK_TFLOPS,
+                    'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,
                     'share_of_unet_call': dom['ms'] / sum(r['ms'] for r in table),
                     'top_instantiation': dict(cls(top), frac=round(top['flops'] / (top['ms'] * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS, 4)),
                     # HBM bytes per launch from the committed rocprofv3 PMC passes over the same UNet call (separate
@@ -447,9 +458,9 @@ def main():
                 folded = {}
                 for r in table:
                     key = _re.sub(r'_M\d+_N\d+_K\d+.*$', '', r['name'])
-                    f_ = folded.setdefault(key, {'name': key, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'bytes': 0.0})
-                    for k_ in ('launches', 'ms', 'flops', 'bytes'):
-                        f_[k_] += r[k_]
+                    f_ = folded.setdefault(key, {'name': key, 'launches': 0, 'ms': 0.0, 'flops': 0.0, 'flops_exec': 0.0, 'bytes': 0.0})
+                    for k_ in ('launches', 'ms', 'flops', 'flops_exec', 'bytes'):
+                        f_[k_] += r.get(k_, r['flops'] if k_ == 'flops_exec' else 0)
                 out['roofline']['per_class'] = [cls(r) for r in sorted(folded.values(), key=lambda r: -r['ms'])]
                 # the weight-streaming GEMMs (M <= 128 rows, i.e. the 8x8 level: every weight byte is a first touch and
                 # there are only 0.13 MFLOP per weight byte): bytes = weights + activations + outputs, against HBM peak
@@ -473,7 +484,7 @@ def main():
             if not args.no_cpu_baseline and args.workload == 'txt2img512':     # the CPU comparator is quoted on the headline config
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 8
+#define SDMI_ABI_VERSION 9
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -72,6 +72,11 @@ int64_t sdmi_unet_workspace_bytes(sdmi_unet* h, int B, int H, int W, int Lctx);
  * compute them once per prompt.  ctx: fp32 [B, Lctx, context_dim]. */
 int sdmi_unet_cache_context(sdmi_unet* h, const float* ctx, int B, int Lctx, void* workspace, int64_t workspace_bytes,
                             void* stream);
+/* The K / V^T caches are handle-owned device buffers of a fixed capacity: sdmi_unet_finalize reserves room for 8 rows x 77
+ * context tokens (the SD-v1 prompt length at the largest batch one call takes).  sdmi_unet_forward NEVER allocates: a
+ * context beyond the capacity fails with a message naming this call.  `reserve_context` grows the capacity (grow-only,
+ * allocates: call it outside the sampling loop); sdmi_unet_cache_context grows it itself when needed. */
+int sdmi_unet_reserve_context(sdmi_unet* h, int B, int Lctx);
 
 /* The timestep path of UNetModel.forward -- timestep_embedding -> time_embed (openaimodel.py:723-724) -> every ResBlock's
  * emb_layers (openaimodel.py:218-224, 22 Linear layers = a 20160 x 1280 fp32 matrix for SD v1) -- depends on the timestep
@@ -278,6 +283,8 @@ int sdmi_tune_dump(char* buf, int buflen);
  * writes a JSON array [{"name","launches","ms","flops","bytes"}] (algorithmic flops / bytes per kernel class) */
 int sdmi_profile_begin(void);
 int sdmi_profile_end(char* json_buf, int json_buf_len);
+/* cache hint used by experiments (tools/bench_prefetch.py): touch every 128-byte line of a device range on `stream` */
+int sdmi_k_prefetch_lines(const void* ptr, int64_t bytes, void* stream);
 /* a device buffer of >= 256 zero bytes owned by the library (out-of-image conv taps read it) */
 const void* sdmi_zero_page(void);
 

@@ -57,9 +57,27 @@ def _x_prev(x, e, tabs, index, noise=None, temperature=1.0):
     return a_prev.sqrt() * pred_x0 + dir_xt + n, pred_x0
 
 
+def _q_sample(alphas_cumprod, x0, step, noise):
+    """DDPM.q_sample (ddpm.py:274-277) with the buffers register_schedule stores as fp32 (ddpm.py:134-136):
+    sqrt(alphas_cumprod)[t] * x0 + sqrt(1 - alphas_cumprod)[t] * noise."""
+    ac = np.asarray(alphas_cumprod, dtype=np.float64)
+    a = float(np.sqrt(ac).astype(np.float32)[step])
+    s = float(np.sqrt(1.0 - ac).astype(np.float32)[step])
+    return a * x0 + s * noise
+
+
+def _mask_blend(alphas_cumprod, img, step, mask, x0, q_noise):
+    """plms.py:147-150 / ddim.py:130-133: img = q_sample(x0, ts) * mask + (1 - mask) * img."""
+    if mask is None:
+        return img
+    return _q_sample(alphas_cumprod, x0, int(step), q_noise) * mask + (1. - mask) * img
+
+
 @torch.no_grad()
-def plms_sample(apply_model, alphas_cumprod, S, x_T, c, scale=1.0, uc=None, record=None):
-    """PLMSSampler.sample/plms_sampling/p_sample_plms, plms.py:57-236 (eta = 0)."""
+def plms_sample(apply_model, alphas_cumprod, S, x_T, c, scale=1.0, uc=None, record=None, mask=None, x0=None, q_noises=None):
+    """PLMSSampler.sample/plms_sampling/p_sample_plms, plms.py:57-236 (eta = 0).
+    `mask` / `x0` / `q_noises`: the inpainting blend in front of every step (plms.py:147-150); q_noises[i] is the noise
+    DDPM.q_sample draws at step i."""
     ts = make_ddim_timesteps(S, len(alphas_cumprod))
     tabs = make_sampling_tables(alphas_cumprod, ts, 0.0)
     time_range = np.flip(ts)
@@ -71,6 +89,7 @@ def plms_sample(apply_model, alphas_cumprod, S, x_T, c, scale=1.0, uc=None, reco
         index = total - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
         t_next = torch.full((b,), int(time_range[min(i + 1, len(time_range) - 1)]), dtype=torch.long)
+        img = _mask_blend(alphas_cumprod, img, step, mask, x0, None if q_noises is None else q_noises[i])
         e_t = _cfg_eps(apply_model, img, t, c, scale, uc)
         if len(old_eps) == 0:
             x_p, _ = _x_prev(img, e_t, tabs, index)
@@ -93,21 +112,25 @@ def plms_sample(apply_model, alphas_cumprod, S, x_T, c, scale=1.0, uc=None, reco
 
 @torch.no_grad()
 def ddim_sample(apply_model, alphas_cumprod, S, x_T, c, scale=1.0, uc=None, eta=0.0, noises=None,
-                record=None):
+                record=None, mask=None, x0=None, q_noises=None):
     """DDIMSampler.sample/ddim_sampling/p_sample_ddim, ddim.py:56-204.
-    `noises`: list of per-step noise tensors when eta > 0 (the reference draws them on device)."""
+    `noises`: list of per-step noise tensors when eta > 0 (the reference draws them on device); `mask` / `x0` /
+    `q_noises`: the inpainting blend in front of every step (ddim.py:130-133)."""
     ts = make_ddim_timesteps(S, len(alphas_cumprod))
     tabs = make_sampling_tables(alphas_cumprod, ts, eta)
-    return _ddim_loop(apply_model, tabs, ts, x_T, c, scale, uc, noises, record)
+    return _ddim_loop(apply_model, tabs, ts, x_T, c, scale, uc, noises, record,
+                      blend=None if mask is None else (alphas_cumprod, mask, x0, q_noises))
 
 
-def _ddim_loop(apply_model, tabs, ts, x, c, scale, uc, noises=None, record=None):
+def _ddim_loop(apply_model, tabs, ts, x, c, scale, uc, noises=None, record=None, blend=None):
     time_range = np.flip(ts)
     total = ts.shape[0]
     b = x.shape[0]
     for i, step in enumerate(time_range):
         index = total - i - 1
         t = torch.full((b,), int(step), dtype=torch.long)
+        if blend is not None:
+            x = _mask_blend(blend[0], x, step, blend[1], blend[2], blend[3][i])
         e_t = _cfg_eps(apply_model, x, t, c, scale, uc)
         x, _ = _x_prev(x, e_t, tabs, index, None if noises is None else noises[i])
         if record is not None:

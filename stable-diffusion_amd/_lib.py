@@ -59,6 +59,7 @@ _SIGS = {
     'sdmi_unet_import_packed': (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_unet_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int, C.c_int, C.c_int]),
     'sdmi_unet_cache_context': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_unet_reserve_context': (C.c_int, [c_ptr, C.c_int, C.c_int]),
     'sdmi_unet_cache_timesteps': (C.c_int, [c_ptr, C.POINTER(C.c_int64), C.c_int, c_ptr]),
     'sdmi_unet_hint_timestep': (C.c_int, [c_ptr, C.c_int64]),
     'sdmi_unet_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -118,6 +119,7 @@ _SIGS = {
     'sdmi_tune_dump': (C.c_int, [C.c_char_p, C.c_int]),
     'sdmi_profile_begin': (C.c_int, []),
     'sdmi_profile_end': (C.c_int, [C.c_char_p, C.c_int]),
+    'sdmi_k_prefetch_lines': (C.c_int, [c_ptr, C.c_int64, c_ptr]),
     'sdmi_zero_page': (c_ptr, []),
 }
 
@@ -140,7 +142,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 8:
+        if lib.sdmi_abi_version() != 9:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -92,6 +92,11 @@ int sdmi_unet_cache_context(sdmi_unet* h, const float* ctx, int B, int Lctx, voi
   return h->impl.run(nullptr, nullptr, nullptr, ctx, nullptr, B, down, down, Lctx, workspace, workspace_bytes,
                      (hipStream_t)stream, false, true, nullptr);
 }
+int sdmi_unet_reserve_context(sdmi_unet* h, int B, int Lctx) {
+  SDMI_CHECK(h, "null argument");
+  SDMI_CHECK(B >= 1 && B <= 8 && Lctx >= 1, "bad context shape");
+  return h->impl.reserve_ctx_cache(B, Lctx);
+}
 int sdmi_unet_cache_timesteps(sdmi_unet* h, const int64_t* t_host, int n, void* stream) {
   SDMI_CHECK(h, "null argument");
   return h->impl.cache_timesteps(t_host, n, (hipStream_t)stream);
@@ -355,6 +360,10 @@ int sdmi_profile_end(char* buf, int buflen) {
   SDMI_CHECK((int)js.size() + 1 <= buflen, "profile buffer too small");
   memcpy(buf, js.c_str(), js.size() + 1);
   return 0;
+}
+int sdmi_k_prefetch_lines(const void* ptr, int64_t bytes, void* stream) {
+  SDMI_CHECK(ptr != nullptr && bytes >= 0, "bad range");
+  return launch_prefetch_lines(ptr, bytes, (hipStream_t)stream);
 }
 const void* sdmi_zero_page(void) {
   const f16* z = nullptr;

@@ -66,6 +66,9 @@ struct IGemmParams {
   int pad = 1;                                         // 3x3 only: 1 = symmetric zero pad; 0 = pad right/bottom only (taps at +0..+2)
   const f16* w = nullptr;                              // [N][K]
   int M = 0, N = 0, K = 0;
+  // K of the reference op when the descriptor executes more (the 3-pass split-fp16 1x1 convs: K = 3 * k_alg); 0 = K.
+  // Only the profiler's algorithmic FLOP count reads it.
+  int k_alg = 0;
   // epilogue
   int mode = EPI_PLAIN;
   const float* bias = nullptr;                         // [N]
@@ -93,7 +96,8 @@ struct IGemmParams {
   // its counter).  Slabs then need splitk * round_up(M, BM) * round_up(N, BN) floats.
   int* splitk_cnt = nullptr; int splitk_cnt_ints = 0;
 #ifdef SDMI_IGEMM_TIMING
-  long long* dbg_times = nullptr;                      // timing build only: 4 s_memtime stamps per workgroup
+  long long* dbg_times = nullptr;                      // timing build only: 6 s_memtime slots per workgroup (5 used)
+  int dbg_abl = 0;                                     // timing build only (SDMI_EPI_ABL): 1 no residual loads, 2 no GroupNorm statistics, 4 no output stores
 #endif
   int splitk_fused = 0;                                // set by the launcher
   int epi_vec = 0;                                     // set by the launcher: 16-byte epilogue (pointer / pitch alignment checked there)
@@ -232,6 +236,9 @@ int launch_quick_gelu(const float* x, f16* out, int64_t n, hipStream_t s);
 int launch_pointwise_nchw(const float* x_nchw, const float* w, const float* bias, float* out_nchw, int B, int Cin, int Cout,
                           int HW, float in_scale, hipStream_t s);
 int launch_softmax_rows(const float* S, f16* P, int rows, int cols, int lds, int ldp, float scale, hipStream_t s);
+
+// cache hint (small.hip): touch every 128-byte line of a device range
+int launch_prefetch_lines(const void* ptr, int64_t bytes, hipStream_t s);
 
 // weight packing (device pointers, fp32 reference layouts -> packed)
 int launch_pack_conv_weight(const float* w_oihw, f16* dst, int O, int I, int KH, int KW, hipStream_t s);  // -> [O][KH][KW][I]

@@ -142,9 +142,16 @@ __device__ __forceinline__ void slab_get(const float* wl, f32x16 (&a)[TN], int l
 // GEGLU, per-head q / k / v^T scatter, split-K slabs, GroupNorm statistics.  `smem` = the block's LDS (free at this point:
 // every LDS-DMA of the block has landed and is no longer read), LDS_BYTES its size.
 template <int BM, int BN, int WARPS_M, int WARPS_N, int LDS_BYTES>
-__device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&acc)[BM / WARPS_M / 32][BN / WARPS_N / 32],
+__device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 (&acc)[BM / WARPS_M / 32][BN / WARPS_N / 32],
                                                const int m0, const int n0, const int split, const int tile_m,
                                                const int tile_n, unsigned char* smem) {
+#ifdef SDMI_IGEMM_TIMING
+  IGemmParams p = p_arg;                                  // timing build: epilogue ablations (wrong results, time only)
+  if (p.dbg_abl & 1) p.residual = nullptr;
+  if (p.dbg_abl & 4) { p.out_f32 = nullptr; p.out_f16 = nullptr; p.out_lo = nullptr; }
+#else
+  const IGemmParams& p = p_arg;
+#endif
   constexpr int NT = WARPS_M * WARPS_N * 64;
   constexpr int WTM = BM / WARPS_M, WTN = BN / WARPS_N;
   constexpr int TM = WTM / 32, TN = WTN / 32;
@@ -350,6 +357,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p, f32x16 (&ac
     // block first combine in LDS (the tile buffers are free now), so the block issues ONE global atomic set per
     // (sample, group) it touched: the global adds, not the arithmetic, are what statistics cost.
     // Needs Hout*Wout % 32 == 0 (a 32-row MFMA tile lies inside one sample); the executor checks it.
+#ifdef SDMI_IGEMM_TIMING
+    if (p.dbg_times && threadIdx.x == 0) p.dbg_times[6 * (size_t)blockIdx.x + 3] = (long long)__builtin_readcyclecounter();
+    if (p.dbg_abl & 2) return;
+#endif
     if (p.gn_n > 0 && !atomic) {
       constexpr int GNB = BM / 32;                        // samples a tile can touch (Hout*Wout >= 32)
       unsigned long long* lacc = (unsigned long long*)smem;                  // [target][sample in tile][group][GN_WORDS]
@@ -861,8 +872,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
 #ifdef SDMI_IGEMM_TIMING
   if (p.dbg_times && tid == 0) {        // (where a workgroup's time goes; blocks that return early in the epilogue are not stamped)
-    long long* d = p.dbg_times + 4 * (size_t)blockIdx.x;
-    d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[3] = (long long)__builtin_readcyclecounter();
+    long long* d = p.dbg_times + 6 * (size_t)blockIdx.x;      // d[3] = after the output stores (written inside the epilogue)
+    d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[4] = (long long)__builtin_readcyclecounter();
   }
 #endif
 #endif  // __HIP_DEVICE_COMPILE__
@@ -928,6 +939,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
   if (c_begin >= c_end) return;
 
   const int tid = threadIdx.x;
+  SDMI_STAMP(dbg_t0);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int cpos = tid & 7, lrow = tid >> 3;
@@ -1052,6 +1064,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
   }
   wait_vmcnt_n(in_flight_ok(8));
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  SDMI_STAMP(dbg_t1);
   f16x8 fa[2][G][TM], fb[2][G][TN];
   int ab[TM];
 #pragma unroll
@@ -1114,7 +1127,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
     }
   }
   wait_vmcnt<0>();
+  SDMI_STAMP(dbg_t2);
   igemm_epilogue<BM, BN, WARPS_M, WARPS_N, LDS_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
+#ifdef SDMI_IGEMM_TIMING
+  if (p.dbg_times && tid == 0) {
+    long long* d = p.dbg_times + 6 * (size_t)blockIdx.x;
+    d[0] = dbg_t0; d[1] = dbg_t1; d[2] = dbg_t2; d[4] = (long long)__builtin_readcyclecounter();
+  }
+#endif
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
@@ -1298,10 +1318,14 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const double src_pix = (double)p.B * p.Hin * p.Win;
   const double out_b = (p.out_f32 ? 4.0 : 0.0) + ((p.out_f16 || p.mode != EPI_PLAIN) ? 2.0 : 0.0);
   const double n_out = p.mode == EPI_GEGLU ? p.N / 2.0 : (double)p.N;
-  ProfScope ps(pname.c_str(), 2.0 * p.M * (double)p.N * p.K,
-               src_pix * (p.c0 + p.c1) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * n_out * out_b +
+  // FLOPs: algorithmic (2 x MACs of the reference op) and executed (the K-concatenated split-fp16 1x1 convs
+  // run three passes); bytes likewise count the reference op's operands once (one fp16 activation read, one weight read)
+  const int k_alg = p.k_alg > 0 ? p.k_alg : p.K;
+  const double cin_alg = p.k_alg > 0 ? (double)p.k_alg : (double)(p.c0 + p.c1 + p.c2);
+  ProfScope ps(pname.c_str(), 2.0 * p.M * (double)p.N * k_alg,
+               src_pix * cin_alg * 2.0 + (double)p.N * k_alg * 2.0 + (double)p.M * n_out * out_b +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
-               stream);
+               stream, 2.0 * p.M * (double)p.N * p.K);
   const int kind = p.ksize == 1 ? KIND_1X1 : (p.up ? KIND_3X3_UP : KIND_3X3);
 #define SDMI_LAUNCH_KIND(K_)                                                                                        \
   do {                                                                                                              \
@@ -1704,13 +1728,19 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
       tile = cands[tcand].tile; splitk = cands[tcand].splitk;
       ev0 = g_tuner.ev(); ev1 = g_tuner.ev();
     } else {
+      // a table entry is taken only if it passes the predicates tune_candidates() generated it under (the key does not carry
+      // the whole geometry, and the file may be stale or hand-edited): otherwise the heuristic below decides
       auto it = g_tuner.table.find(tkey);
-      if (it != g_tuner.table.end() &&
-          (it->second.splitk == 1 || (can_split && splitk_ws_need(p, kTiles[it->second.tile].bm, kTiles[it->second.tile].bn,
-                                                                  it->second.splitk) <= p.splitk_ws_floats)) &&
-          (p.mode != EPI_GEGLU || tile_tn_even(it->second.tile)) &&
-          (!tile_is_halo(it->second.tile) || halo_supported(p, kTiles[it->second.tile].bm))) {
-        tile = it->second.tile; splitk = it->second.splitk;
+      if (it != g_tuner.table.end()) {
+        const int tt = it->second.tile, sk = it->second.splitk;
+        const bool halo = tile_is_halo(tt);
+        const bool ws_ok = sk == 1 || (can_split && splitk_ws_need(p, kTiles[tt].bm, kTiles[tt].bn, sk) <= p.splitk_ws_floats);
+        const bool split_ok = splitk != 0 ? (sk == splitk && ws_ok)                      // the caller pinned the split
+                                          : (sk == 1 || (ws_ok && nkt / sk >= 4 && (halo || (sk != 5 && sk != 10)) &&
+                                                         (!halo || (nkt / 9) % sk == 0)));
+        if (split_ok && (p.mode != EPI_GEGLU || tile_tn_even(tt)) && (!halo || halo_supported(p, kTiles[tt].bm))) {
+          tile = tt; splitk = sk;
+        }
       }
     }
   }
@@ -1739,26 +1769,30 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
   if (ev0) SDMI_HIP_OK(hipEventRecord(ev0, stream));
 #ifdef SDMI_IGEMM_TIMING
   static const char* dbg_path = getenv("SDMI_IGEMM_TIMING");       // debug: per-workgroup phase timing appended to this file
+  static const int dbg_abl = env_int("SDMI_EPI_ABL", 0);
   static long long* dbg_buf = nullptr;
+  constexpr int DBG_WG = 16384;
   IGemmParams pd = p;
-  if (dbg_path && !tile_is_halo(tile)) {
-    if (!dbg_buf) SDMI_HIP_OK(hipMalloc((void**)&dbg_buf, 4 * 16384 * sizeof(long long)));
-    SDMI_HIP_OK(hipMemsetAsync(dbg_buf, 0, 4 * 16384 * sizeof(long long), stream));
+  pd.dbg_abl = dbg_abl;
+  if (dbg_path) {
+    if (!dbg_buf) SDMI_HIP_OK(hipMalloc((void**)&dbg_buf, 6 * DBG_WG * sizeof(long long)));
+    SDMI_HIP_OK(hipMemsetAsync(dbg_buf, 0, 6 * DBG_WG * sizeof(long long), stream));
     pd.dbg_times = dbg_buf;
   }
   const int rc = launch_tile(tile, pd, dma, splitk, stream);
   if (dbg_path && pd.dbg_times && rc == 0) {
     SDMI_HIP_OK(hipStreamSynchronize(stream));
-    std::vector<long long> h(4 * 16384);
+    std::vector<long long> h(6 * DBG_WG);
     SDMI_HIP_OK(hipMemcpy(h.data(), dbg_buf, h.size() * sizeof(long long), hipMemcpyDeviceToHost));
-    std::vector<long long> pro, loop, epi, start;
+    std::vector<long long> pro, loop, epi, sto, start;
     long long tmin = 0, tmax = 0;
-    for (int b = 0; b < 16384; ++b) {
-      const long long* d = &h[4 * b];
-      if (d[3] == 0) continue;
-      pro.push_back(d[1] - d[0]); loop.push_back(d[2] - d[1]); epi.push_back(d[3] - d[2]);
+    for (int b = 0; b < DBG_WG; ++b) {
+      const long long* d = &h[6 * b];
+      if (d[4] == 0) continue;
+      pro.push_back(d[1] - d[0]); loop.push_back(d[2] - d[1]); epi.push_back(d[4] - d[2]);
+      sto.push_back(d[3] ? d[3] - d[2] : d[4] - d[2]);           // epilogue up to the end of the output stores
       if (start.empty() || d[0] < tmin) tmin = d[0];
-      if (d[3] > tmax) tmax = d[3];
+      if (d[4] > tmax) tmax = d[4];
       start.push_back(d[0]);
     }
     if (!pro.empty()) {
@@ -1768,9 +1802,9 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
       for (long long t : start) late = std::max(late, t - tmin);
       if (FILE* f = fopen(dbg_path, "a")) {
         const int nkt_split = (p.K / BK + std::max(splitk, 1) - 1) / std::max(splitk, 1);
-        fprintf(f, "M%d N%d K%d k%d mode%d tile%d split%d blocks%zu k-tiles/block %d | shader cycles: span %lld last-start %lld | median prologue %lld loop %lld epilogue %lld | max loop %lld | loop cycles per k-tile %.1f\n",
-                p.M, p.N, p.K, p.ksize, p.mode, tile, splitk, pro.size(), nkt_split, tmax - tmin, late, med(pro), med(loop), med(epi), mx(loop),
-                (double)med(loop) / nkt_split);
+        fprintf(f, "M%d N%d K%d k%d mode%d tile%d split%d res%d gn%d blocks%zu k-tiles/block %d | shader cycles: span %lld last-start %lld | median prologue %lld loop %lld epilogue %lld (stores %lld) | max loop %lld max epi %lld | loop cycles per k-tile %.1f\n",
+                p.M, p.N, p.K, p.ksize, p.mode, tile, splitk, p.residual ? 1 : 0, p.gn_n, pro.size(), nkt_split, tmax - tmin, late, med(pro), med(loop),
+                med(epi), med(sto), mx(loop), mx(epi), (double)med(loop) / nkt_split);
         fclose(f);
       }
     }

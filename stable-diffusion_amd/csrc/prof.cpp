@@ -8,15 +8,15 @@
 
 namespace sdmi {
 namespace {
-struct Rec { std::string name; double flops, bytes; hipEvent_t e0, e1; };
+struct Rec { std::string name; double flops, flops_exec, bytes; hipEvent_t e0, e1; };
 bool g_on = false;
 std::vector<Rec> g_recs;
 }  // namespace
 
 bool prof_enabled() { return g_on; }
 
-int prof_record_begin(const char* name, double flops, double bytes, hipStream_t s) {
-  Rec r; r.name = name; r.flops = flops; r.bytes = bytes;
+int prof_record_begin(const char* name, double flops, double bytes, hipStream_t s, double flops_exec) {
+  Rec r; r.name = name; r.flops = flops; r.flops_exec = flops_exec < 0 ? flops : flops_exec; r.bytes = bytes;
   (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
@@ -36,13 +36,13 @@ int prof_begin() {
 int prof_end(std::string* json) {
   g_on = false;
   SDMI_HIP_OK(hipDeviceSynchronize());
-  struct Agg { int n = 0; double ms = 0, flops = 0, bytes = 0; };
+  struct Agg { int n = 0; double ms = 0, flops = 0, flops_exec = 0, bytes = 0; };
   std::map<std::string, Agg> agg;
   for (auto& r : g_recs) {
     float ms = 0.f;
     (void)hipEventElapsedTime(&ms, r.e0, r.e1);
     Agg& a = agg[r.name];
-    a.n += 1; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+    a.n += 1; a.ms += ms; a.flops += r.flops; a.flops_exec += r.flops_exec; a.bytes += r.bytes;
     (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
   }
   g_recs.clear();
@@ -53,7 +53,7 @@ int prof_end(std::string* json) {
     if (!first) os << ",";
     first = false;
     os << "{\"name\":\"" << kv.first << "\",\"launches\":" << kv.second.n << ",\"ms\":" << kv.second.ms
-       << ",\"flops\":" << kv.second.flops << ",\"bytes\":" << kv.second.bytes << "}";
+       << ",\"flops\":" << kv.second.flops << ",\"flops_exec\":" << kv.second.flops_exec << ",\"bytes\":" << kv.second.bytes << "}";
   }
   os << "]";
   *json = os.str();

@@ -543,6 +543,22 @@ int launch_pack_conv_weight(const float* w, f16* dst, int O, int I, int KH, int 
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
+// Touch one dword of every 128-byte line of [ptr, ptr + bytes): pulls the range through this XCD's L2 into the Infinity Cache.
+// The loaded values are only kept alive (never stored).  A cache hint: no correctness role.
+__global__ void __launch_bounds__(256) prefetch_lines_kernel(const unsigned* p, long long nlines) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nlines) return;
+  const unsigned v = __builtin_nontemporal_load(p + i * 32);
+  asm volatile("" ::"v"(v));
+}
+int launch_prefetch_lines(const void* ptr, int64_t bytes, hipStream_t s) {
+  const long long nlines = bytes / 128;
+  if (nlines <= 0) return 0;
+  hipLaunchKernelGGL(prefetch_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, s, (const unsigned*)ptr, nlines);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
 int launch_pack_conv_out(const float* w, float* dst, int O, int I, hipStream_t s) {
   const int64_t total = (int64_t)O * I * 9;
   hipLaunchKernelGGL(pack_conv_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, 3, 3);

@@ -344,6 +344,7 @@ int UNet::finalize() {
     owned_.push_back(zero_);
     SDMI_HIP_OK(hipMemset(zero_, 0, 4096));
   }
+  if (reserve_ctx_cache(8, 77)) return -1;       // default K/V capacity (a no-op once reserved)
   finalized_ = true;
   return 0;
 }
@@ -651,22 +652,39 @@ struct Fwd : FwdBase {
   }
 };
 
-int UNet::ensure_ctx_cache(int B, int Lctx) {
-  if (ctx_B_ == B && ctx_L_ == Lctx) return 0;
-  const int Lp = (int)round_up(Lctx, 8);
+// Cross-attention K / V^T caches of every transformer block: capacity-sized device buffers owned by the handle.  They are
+// allocated by finalize() for the default capacity (8 rows x 80 padded context tokens: SD v1's 77-token prompts at the largest
+// batch one call takes) and grown only by reserve_ctx_cache() -- sdmi_unet_reserve_context / sdmi_unet_cache_context, both off
+// the hot path.  sdmi_unet_forward never allocates: a context beyond the capacity is an error that names the remedy.
+int UNet::reserve_ctx_cache(int B, int Lctx) {
+  const int64_t need = (int64_t)B * round_up(Lctx, 8);          // (B * Lctx * C <= B * Lp * C: one capacity covers K and V^T)
+  if (need <= ctx_cap_) return 0;
   auto each = [&](Layer& L) -> int {
     if (L.kind != L_ATTN) return 0;
     for (auto& T : L.tb) {
       if (T.ck) { (void)hipFree(T.ck); T.ck = nullptr; }
       if (T.cvt) { (void)hipFree(T.cvt); T.cvt = nullptr; }
-      SDMI_HIP_OK(hipMalloc((void**)&T.ck, (size_t)B * Lctx * L.cin * sizeof(f16)));
-      SDMI_HIP_OK(hipMalloc((void**)&T.cvt, (size_t)B * L.cin * Lp * sizeof(f16)));
+      SDMI_HIP_OK(hipMalloc((void**)&T.ck, (size_t)need * L.cin * sizeof(f16)));
+      SDMI_HIP_OK(hipMalloc((void**)&T.cvt, (size_t)need * L.cin * sizeof(f16)));
     }
     return 0;
   };
   for (auto& blk : input_blocks_) for (auto& L : blk) if (each(L)) return -1;
   for (auto& L : middle_) if (each(L)) return -1;
   for (auto& blk : output_blocks_) for (auto& L : blk) if (each(L)) return -1;
+  ctx_cap_ = need; ctx_B_ = 0; ctx_L_ = 0; ctx_valid_ = false;
+  return 0;
+}
+
+// bind the cache to the shape of this call: no allocation; a different shape only invalidates the cached contents
+int UNet::ensure_ctx_cache(int B, int Lctx, bool may_grow) {
+  if (ctx_B_ == B && ctx_L_ == Lctx) return 0;
+  const int64_t need = (int64_t)B * round_up(Lctx, 8);
+  if (need > ctx_cap_) {
+    if (may_grow) { if (reserve_ctx_cache(B, Lctx)) return -1; }
+    else return fail("context of " + std::to_string(B) + " x " + std::to_string(Lctx) + " tokens exceeds the reserved K/V capacity (" +
+                     std::to_string(ctx_cap_) + " padded rows): call sdmi_unet_reserve_context(h, B, Lctx) once, outside the sampling loop");
+  }
   ctx_B_ = B; ctx_L_ = Lctx; ctx_valid_ = false;
   return 0;
 }
@@ -725,6 +743,13 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
   const int down = 1 << (cfg_.n_levels - 1);
   SDMI_CHECK(H % down == 0 && W % down == 0, "H and W must be divisible by 2^(levels-1) (the UNet's skip concat requires it)");
 
+  // The timestep hint is an announcement about THIS call only: consume it up front, so that a call that fails on any of the
+  // early returns below (workspace too small, missing context, a launch error) cannot leave it behind for an unrelated
+  // later forward, which would then silently take the table row of the old timestep.  (Sizing and context-only calls
+  // do not touch the timestep path and leave the hint alone.)
+  const int hint_row = emb_hint_row_;
+  if (!dry && !ctx_only) emb_hint_row_ = -1;
+
   Fwd f;
   f.u = this; f.s = stream; f.dry = dry; f.B = B; f.Lctx = Lctx; f.zero = zero_; f.precise_1x1 = precise_1x1_;
   if (side_stream_ && !dry && !prof_enabled()) {      // (the per-launch profiler times launches on one stream)
@@ -751,7 +776,7 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       SDMI_CHECK(workspace != nullptr, "workspace is NULL");
       f.persist.base = (char*)workspace; f.persist.cap = (size_t)persist_bytes;
       f.scratch.base = (char*)workspace + persist_bytes; f.scratch.cap = (size_t)scratch_bytes;
-      if (ensure_ctx_cache(B, Lctx)) return -1;
+      if (ensure_ctx_cache(B, Lctx, ctx_only)) return -1;
     }
     const int mc = cfg_.model_channels;
     if (f.begin_pass((int64_t)12 << 20)) return -1;    // 48 MB of fp32 split-K slabs (largest user: 8 x 512 x 1280)
@@ -776,9 +801,9 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       float* emb = f.P<float>((size_t)B * te_);
       f.emb_all = f.P<float>((size_t)B * emb_total_);
       f.emb_ld = emb_total_;
-      if (!d && emb_hint_row_ >= 0 && emb_hint_row_ < (int)emb_tab_t_.size()) {
+      if (!d && t_i64 != nullptr && hint_row >= 0 && hint_row < (int)emb_tab_t_.size()) {
         // every row has the hinted timestep and its emb_layers outputs are in the table: one shared row, nothing to launch
-        f.emb_all = emb_tab_ + (size_t)emb_hint_row_ * emb_total_;
+        f.emb_all = emb_tab_ + (size_t)hint_row * emb_total_;
         f.emb_ld = 0;
       } else if (!d) {
         int r = launch_timestep_embedding(t_i64, t_f32, temb, B, mc, stream);
@@ -817,7 +842,6 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     else {
       SDMI_CHECK(!f.persist.overflow && !f.scratch.overflow, "internal: arena overflow");
       if (have_ctx) ctx_valid_ = true;
-      if (!ctx_only) emb_hint_row_ = -1;       // the hint was for this call
     }
   }
   if (bytes_needed) *bytes_needed = persist_bytes + scratch_bytes;

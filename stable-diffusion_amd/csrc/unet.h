@@ -175,7 +175,7 @@ struct FwdBase {
   IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch) {
     IGemmParams p = dense(hi, M, K, w, N, rows_per_batch);
     if (precise_1x1) {
-      p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K;
+      p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K; p.k_alg = K;
     }
     return p;
   }
@@ -268,6 +268,8 @@ class UNet {
   // emb_all rows of a list of integer timesteps, computed in one batch (include/sdmi.h: sdmi_unet_cache_timesteps);
   // hint: the next run()'s rows all have timestep t
   int cache_timesteps(const int64_t* t_host, int n, hipStream_t stream);
+  // grow-only capacity of the cross-attention K / V^T caches (allocates; never called by run() on the forward path)
+  int reserve_ctx_cache(int B, int Lctx);
   int hint_timestep(int64_t t);
 
   const std::vector<WeightSlot>& slots() const { return slots_; }
@@ -289,7 +291,7 @@ class UNet {
               void** dst2 = nullptr);
   int dev_alloc(void** dst, size_t bytes);
   size_t slot_bytes(const WeightSlot& s) const;
-  int ensure_ctx_cache(int B, int Lctx);
+  int ensure_ctx_cache(int B, int Lctx, bool may_grow);
   GnPlan gn_plan_;           // GroupNorm-statistics fusion plan of the current forward (rebuilt by its dry pass)
   bool side_stream_ = false;    // SDMI_SIDE_STREAM=1: ResBlock skip convolutions on a side stream (measured 3 % slower)
   hipStream_t side_ = nullptr; hipEvent_t side_ev_[32] = {};
@@ -305,6 +307,7 @@ class UNet {
   float *out_gamma_ = nullptr, *out_beta_ = nullptr, *out_w_ = nullptr, *out_b_ = nullptr;
   bool finalized_ = false;
   int ctx_B_ = 0, ctx_L_ = 0; bool ctx_valid_ = false;
+  int64_t ctx_cap_ = 0;      // K / V^T cache capacity in padded context rows (B * round_up(Lctx, 8))
   // timestep table: [n][emb_total] fp32 rows + scratch for one chunk of 8 timesteps (grow-only device buffer)
   float* emb_tab_ = nullptr; size_t emb_tab_floats_ = 0;
   int64_t* emb_tab_tdev_ = nullptr; size_t emb_tab_tcap_ = 0;

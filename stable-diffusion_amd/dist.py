@@ -16,7 +16,11 @@ def init_from_env(backend=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', str(rank)))
-    if world > 1 and not dist.is_initialized():
+    # A launcher (torchrun) exports RANK / WORLD_SIZE also for ONE process: the group is then initialised as well (a
+    # world of size 1 is legal), so that `torchrun --nproc-per-node 1 bench.py` exercises exactly the code path of N > 1 --
+    # RCCL communicator setup, the all_gather of the latents, the all_reduce of the timing -- on a single GPU.
+    launched = 'RANK' in os.environ and 'WORLD_SIZE' in os.environ
+    if (world > 1 or launched) and not dist.is_initialized():
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
@@ -39,7 +43,7 @@ def gather_latents(local, n_total, rank=None, world=None):
         world = dist.get_world_size() if dist.is_initialized() else 1
     if rank is None:
         rank = dist.get_rank() if dist.is_initialized() else 0
-    if world == 1:
+    if world == 1 and not dist.is_initialized():
         return local
     n_max = (n_total + world - 1) // world
     pad = torch.zeros((n_max,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
@@ -56,7 +60,7 @@ def gather_latents(local, n_total, rank=None, world=None):
 
 def max_over_ranks(value, device):
     """Scalar max across ranks (used for the timed region of bench.py)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not dist.is_initialized():
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -65,6 +65,12 @@ class _SamplerBase(object):
     def register_buffer(self, name, attr):   # kept for API compatibility (plms.py:18-22)
         setattr(self, name, attr)
 
+    @staticmethod
+    def _noise_like(shape, device):
+        """util.py noise_like (ddim.py:200): one draw from the device RNG per step.  A separate method so that a parity test
+        can hand out the recorded sequence of a reference run (tests/test_sampler_gpu.py)."""
+        return torch.randn(shape, device=device)
+
     def _tables(self, ddim_num_steps, ddim_discretize, ddim_eta):
         self.ddim_timesteps = make_ddim_timesteps(ddim_num_steps, self.ddpm_num_timesteps, ddim_discretize)
         ac = self.model.alphas_cumprod
@@ -118,11 +124,14 @@ class _SamplerBase(object):
         if cfg:
             x_in[b:].copy_(img)
         t_in = torch.full((x_in.shape[0],), t_val, device=x_in.device, dtype=t_dtype)
-        if t_dtype == torch.long:
-            unet = self._hip_unet()
+        unet = self._hip_unet() if t_dtype == torch.long else None
+        if unet is not None:
+            unet.hint_timestep(int(t_val))          # every row of t_in is this int: rows of the timestep table, if cached
+        try:
+            out = self.model.apply_model(x_in, t_in, c_in)
+        finally:
             if unet is not None:
-                unet.hint_timestep(int(t_val))      # every row of t_in is this int: rows of the timestep table, if cached
-        out = self.model.apply_model(x_in, t_in, c_in)
+                unet.clear_timestep_hint()          # (consumed by forward(); still set only if apply_model raised before it)
         return out.float().contiguous()
 
 
@@ -263,7 +272,7 @@ class DDIMSamplerHIP(_SamplerBase):
             # too, so the device RNG stream stays where the reference's is (the x_T of a later n_iter comes from it);
             # the kernel only reads it when sigma_t != 0.  The reference multiplies sigma_t * noise first, then the
             # temperature: the step kernel takes the product noise * temperature (identical at the default temperature 1).
-            noise = torch.randn(img.shape, device=device) * temperature
+            noise = self._noise_like(img.shape, device) * temperature
             if noise_dropout > 0.:
                 noise = torch.nn.functional.dropout(noise, p=noise_dropout)
             noise = noise.float().contiguous() if float(self._tab['sigmas'][index]) != 0.0 else None

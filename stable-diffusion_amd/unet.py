@@ -204,14 +204,33 @@ class UNetModelHIP(nn.Module):
         self._ctx_ref = None
         return self
 
+    _WS_KEEP = 4      # workspaces kept per module: a chunked batch (8 + 2 rows) or txt2img + img2img shapes alternate between a few
+
     def _workspace(self, B, H, W, L, device):
+        """Caller-owned scratch of sdmi_unet_forward for this shape.  A few shapes are kept (most recently used first), so
+        a batch evaluated in chunks of different sizes does not re-size and re-allocate its workspace on every step."""
         key = (B, H, W, L, str(device))
-        if self._ws is None or self._ws[0] != key:
-            need = self._handle.lib.sdmi_unet_workspace_bytes(self._handle.h, B, H, W, L)
-            if need <= 0:
-                _lib.check(-1)
-            self._ws = (key, torch.empty(int(need), dtype=torch.uint8, device=device))
-        return self._ws[1]
+        if self._ws is None:
+            self._ws = []
+        for i, (k, buf) in enumerate(self._ws):
+            if k == key:
+                if i:
+                    self._ws.insert(0, self._ws.pop(i))
+                return buf
+        need = self._handle.lib.sdmi_unet_workspace_bytes(self._handle.h, B, H, W, L)
+        if need <= 0:
+            _lib.check(-1)
+        buf = torch.empty(int(need), dtype=torch.uint8, device=device)
+        self._ws.insert(0, (key, buf))
+        del self._ws[self._WS_KEEP:]
+        return buf
+
+    def _reserve_context(self, B, L):
+        """K / V^T cache capacity of the library (grow-only; sdmi_unet_forward itself never allocates)."""
+        need = B * ((L + 7) // 8 * 8)
+        if need > getattr(self, '_ctx_cap', 8 * 80):
+            _lib.check(self._handle.lib.sdmi_unet_reserve_context(self._handle.h, B, L))
+            self._ctx_cap = need
 
     # ---- context pinning (used by the HIP samplers) ------------------------------------------------------------
     def pin_context(self, context):
@@ -230,6 +249,7 @@ class UNetModelHIP(nn.Module):
             return
         down = 2 ** (len(self.channel_mult) - 1)
         ws = self._workspace(B, down, down, L, context.device)
+        self._reserve_context(B, L)
         ctx32 = context.detach().float().contiguous()
         _lib.check(self._handle.lib.sdmi_unet_cache_context(self._handle.h, ctx32.data_ptr(), B, L, ws.data_ptr(),
                                                             ws.numel(), _lib.stream_ptr()))
@@ -260,17 +280,25 @@ class UNetModelHIP(nn.Module):
         very int, plms.py:137, ddim.py:148): take the cached rows if cache_timesteps() covered t."""
         self._t_hint = int(t)
 
+    def clear_timestep_hint(self):
+        """Drop a hint that was not consumed (the samplers call this when apply_model raised before reaching forward())."""
+        self._t_hint = None
+
     def _pinned_matches(self, context):
         ref, ver, saved = self._pinned_ctx
         if context is ref and context._version == ver:
             return True
-        return bool(torch.equal(context.detach().float(), saved))
+        c = context.detach()
+        return bool(torch.equal(c if c.dtype == torch.float32 else c.float(), saved))
 
     # ---- UNetModel.forward (openaimodel.py:710-742) ----------------------------------------------------------
     MAX_ROWS = 8      # rows per library call (sdmi_unet_forward); larger batches are split, rows are independent
 
     @torch.no_grad()
     def forward(self, x, timesteps=None, context=None, y=None, **kwargs):
+        # one-shot: the hint describes THIS call; it is consumed before anything below can raise, so a failed call cannot
+        # leave it behind for a later, unrelated forward
+        t_hint, self._t_hint = getattr(self, '_t_hint', None), None
         assert y is None, 'must specify y if and only if the model is class-conditional'
         if not x.is_cuda:
             raise RuntimeError('UNetModelHIP runs on an MI355X device tensor only (no CPU fallback)')
@@ -281,7 +309,6 @@ class UNetModelHIP(nn.Module):
         B, Cin, H, W = x.shape
         assert Cin == self.in_channels
         assert timesteps.shape == (B,)
-        t_hint, self._t_hint = getattr(self, '_t_hint', None), None          # (one-shot: consumed by this call)
         if t_hint is not None and os.environ.get('SDMI_CHECK_T_HINT') == '1':
             # debug: the hint is the caller's assertion about a device tensor; this check costs a device round trip
             if not bool((timesteps == t_hint).all()):
@@ -316,6 +343,7 @@ class UNetModelHIP(nn.Module):
         ctx32 = None
         if not reuse:
             ctx32 = context.detach().float().contiguous()
+            self._reserve_context(B, L)
         out = torch.empty((B, self.out_channels, H, W), dtype=torch.float32, device=x.device)
         if t_hint is not None and t_i64 is not None:
             _lib.check(self._handle.lib.sdmi_unet_hint_timestep(self._handle.h, int(t_hint)))
@@ -323,10 +351,10 @@ class UNetModelHIP(nn.Module):
             self._handle.h, x32.data_ptr(), _lib.ptr(t_i64), _lib.ptr(t_f32), _lib.ptr(ctx32), out.data_ptr(),
             B, H, W, L, ws.data_ptr(), ws.numel(), _lib.stream_ptr()))
         if not reuse:
-            # the library's K/V cache now holds THIS context: a pin for other contents is void, and the identity
-            # shortcut only applies to un-chunked calls
-            if self._pinned == (B, L):
-                self._pinned, self._pinned_ctx = None, None
+            # the library has ONE K/V cache and it now holds THIS context: any pin is void -- whatever its shape (a call with
+            # another (B, L), or a chunk of a larger batch, displaced it too) -- and the identity shortcut only applies to
+            # un-chunked calls.  The next pinned-shape forward then passes its context again instead of ctx = NULL.
+            self._pinned, self._pinned_ctx = None, None
             if allow_reuse:
                 self._ctx_ref, self._ctx_ver, self._ctx_shape = context, context._version, (B, L)
             else:

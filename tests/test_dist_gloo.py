@@ -56,6 +56,35 @@ def test_single_process_passthrough():
     assert sd_dist.shard(['a', 'b', 'c'], 1, 2) == [(1, 'b')]
 
 
+def _world1_worker(port, q):
+    """A launcher exports RANK / WORLD_SIZE also for one process (torchrun --nproc-per-node 1): the group is initialised and
+    the gather / timing reduce go through the collectives -- the code path the 1-GPU RCCL run of bench.py takes."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    import bench
+    from stable_diffusion_amd import dist as sd_dist
+    r, w, _ = sd_dist.init_from_env(backend='gloo')
+    inited = dist.is_initialized() and dist.get_world_size() == 1
+    x = torch.arange(3 * 4 * 8 * 8, dtype=torch.float32).reshape(3, 4, 8, 8)
+    full = sd_dist.gather_latents(x, 3, r, w)
+    went_through_collective = full is not x and torch.equal(full, x)
+    mx = sd_dist.max_over_ranks(7.5, torch.device('cpu'))
+    elapsed, lat, img, allz = bench.timed_steps(lambda s: (torch.full((1, 4, 8, 8), float(s)), torch.zeros(1, 3, 8, 8)), 2, 1, w, r,
+                                                torch.device('cpu'))
+    ok = inited and went_through_collective and mx == 7.5 and allz.shape == (1, 4, 8, 8) and float(allz.mean()) == 1.0
+    q.put(bool(ok))
+    dist.destroy_process_group()
+
+
+def test_launched_world_of_one_initialises_the_group():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_world1_worker, args=(_free_port(), q))
+    p.start()
+    assert q.get(timeout=180) is True
+    p.join(timeout=60)
+    assert p.exitcode == 0
+
+
 def _bench_worker(rank, world, port, q):
     """bench.py's timed region (barrier-bracketed steps, one latent all_gather per step, max-over-ranks time) with a fake
     per-step workload: rank 1 is slower, so the reported time must be rank 1's on both ranks."""

@@ -85,6 +85,26 @@ def test_oracle_samplers_match_reference_golden(golden_dir):
     assert (out - torch.from_numpy(G['img2img_out'])).abs().max().item() < 1e-6
 
 
+def test_oracle_sampler_variants_match_reference_golden(golden_dir):
+    """DDIM eta = 0.5 and the mask / x0 blend of PLMS and DDIM against reference runs with recorded noise
+    (tests/golden/samplers2.npz, oracle/make_golden_samplers2.py)."""
+    G = np.load(os.path.join(golden_dir, 'samplers2.npz'))
+    ac, S = G['alphas_cumprod'], int(G['S'])
+    x_T, c, uc, x0, mask = (torch.from_numpy(G[k]) for k in ('x_T', 'c', 'uc', 'x0', 'mask'))
+    noises = [torch.from_numpy(n) for n in G['noises']]
+    q_noises = [torch.from_numpy(n) for n in G['q_noises']]
+    out = samplers_ref.ddim_sample(_stub, ac, S, x_T, c, 7.5, uc, eta=0.5, noises=noises)
+    assert (out - torch.from_numpy(G['ddim_eta05'])).abs().max().item() < 1e-6
+    out = samplers_ref.plms_sample(_stub, ac, S, x_T, c, 7.5, uc, mask=mask, x0=x0, q_noises=q_noises)
+    assert (out - torch.from_numpy(G['plms_mask'])).abs().max().item() < 1e-6
+    out = samplers_ref.ddim_sample(_stub, ac, S, x_T, c, 7.5, uc, mask=mask, x0=x0, q_noises=q_noises)
+    assert (out - torch.from_numpy(G['ddim_mask'])).abs().max().item() < 1e-6
+    # the variants are really exercised: each differs from the default trajectory
+    base = samplers_ref.ddim_sample(_stub, ac, S, x_T, c, 7.5, uc)
+    assert (base - torch.from_numpy(G['ddim_eta05'])).abs().max().item() > 0.05
+    assert (base - torch.from_numpy(G['ddim_mask'])).abs().max().item() > 0.05
+
+
 # ---- first stage (SURVEY.md 8 f-1): oracle/vae_ref.py against the reference Encoder / Decoder goldens -----------------
 @pytest.mark.parametrize('case', ['tiny_8x8', 'tiny_8x24', 'small_16x16', 'sd_8x8'])
 def test_oracle_vae_decode_matches_reference_golden(case, golden_dir):

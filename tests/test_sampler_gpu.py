@@ -87,6 +87,62 @@ def test_img2img_encode_decode(G):
     assert len(model.calls) == 37 and model.calls[0] == 721 and err < 2e-4
 
 
+# ---- sampler variants beyond the script defaults, against reference runs with recorded noise (tests/golden/samplers2.npz,
+# oracle/make_golden_samplers2.py): DDIM eta > 0 (ddim.py:195-203) and the mask / x0 blend (plms.py:147-150, ddim.py:130-133)
+@pytest.fixture(scope='module')
+def G2(golden_dir):
+    return np.load(os.path.join(golden_dir, 'samplers2.npz'))
+
+
+class StubLDq(StubLD):
+    """+ DDPM.q_sample (ddpm.py:274-277), its noise handed out from the recorded sequence of the reference run"""
+
+    def __init__(self, betas, ac, q_noises):
+        super().__init__(betas, ac)
+        self.sqrt_alphas_cumprod = torch.tensor(np.sqrt(ac.astype(np.float64)).astype(np.float32)).cuda()
+        self.sqrt_one_minus_alphas_cumprod = torch.tensor(np.sqrt(1.0 - ac.astype(np.float64)).astype(np.float32)).cuda()
+        self._q = [torch.from_numpy(n).cuda() for n in q_noises]
+
+    def q_sample(self, x_start, t, noise=None):
+        noise = self._q.pop(0) if noise is None else noise
+        sh = (t.shape[0],) + (1,) * (x_start.dim() - 1)
+        return self.sqrt_alphas_cumprod.gather(-1, t).reshape(sh) * x_start + \
+            self.sqrt_one_minus_alphas_cumprod.gather(-1, t).reshape(sh) * noise
+
+
+def test_ddim_eta_trajectory(G2):
+    """DDIM with eta = 0.5: sigma_t up to 0.39, the noise term of ddim.py:200-203 is live on every step."""
+    from stable_diffusion_amd import DDIMSamplerHIP
+    S = int(G2['S'])
+    model = StubLD(G2['betas'], G2['alphas_cumprod'])
+    smp = DDIMSamplerHIP(model)
+    seq = [torch.from_numpy(n).cuda() for n in G2['noises']]
+    smp._noise_like = lambda shape, device: seq.pop(0)
+    x_T, c, uc = (torch.from_numpy(G2[k]).cuda() for k in ('x_T', 'c', 'uc'))
+    out, _ = smp.sample(S=S, batch_size=2, shape=[4, 8, 8], conditioning=c, verbose=False, x_T=x_T,
+                        unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.5)
+    err = (out.cpu() - torch.from_numpy(G2['ddim_eta05'])).abs().max().item()
+    print(f'[ddim eta=0.5 S={S}] calls {len(model.calls)} sigma max {float(smp.ddim_sigmas.max()):.3f} max-abs {err:.3e}')
+    assert not seq and len(model.calls) == S and float(smp.ddim_sigmas.max()) > 0.3
+    assert err < 2e-4
+
+
+@pytest.mark.parametrize('kind', ['plms', 'ddim'])
+def test_mask_blend_trajectory(G2, kind):
+    """inpainting blend in front of every step: img = q_sample(x0, ts) * mask + (1 - mask) * img"""
+    from stable_diffusion_amd import DDIMSamplerHIP, PLMSSamplerHIP
+    S = int(G2['S'])
+    model = StubLDq(G2['betas'], G2['alphas_cumprod'], G2['q_noises'])
+    smp = (PLMSSamplerHIP if kind == 'plms' else DDIMSamplerHIP)(model)
+    x_T, c, uc, x0, mask = (torch.from_numpy(G2[k]).cuda() for k in ('x_T', 'c', 'uc', 'x0', 'mask'))
+    out, _ = smp.sample(S=S, batch_size=2, shape=[4, 8, 8], conditioning=c, verbose=False, x_T=x_T, mask=mask, x0=x0,
+                        unconditional_guidance_scale=7.5, unconditional_conditioning=uc, eta=0.0)
+    err = (out.cpu() - torch.from_numpy(G2[f'{kind}_mask'])).abs().max().item()
+    print(f'[{kind} mask blend S={S}] calls {len(model.calls)} max-abs {err:.3e}')
+    assert not model._q and len(model.calls) == S + (1 if kind == 'plms' else 0)
+    assert err < 2e-4
+
+
 def test_plms_end_to_end_with_hip_unet():
     """10-step PLMS, CFG 7.5, through LatentDiffusionHIP + UNetModelHIP vs the oracle loop driving the oracle UNet."""
     from oracle import samplers_ref, unet_ref

@@ -14,13 +14,13 @@ pytestmark = pytest.mark.gpu
 from oracle.plan import SD_V1, SMALL40, TINY  # noqa: E402
 from oracle.weights import make_inputs, make_state_dict  # noqa: E402
 
-TOL = 1e-3            # north_star: eps of the SD-v1 UNet vs the reference, max-abs
-# The TINY stand-in (64 model channels: GroupNorm groups of 2 channels, d_head 32, K = 64..256 dot products) exists only to
-# keep CPU-side fixtures small.  Its per-output error is a little larger than the real architecture's (rms 1.8e-4 vs
-# 1.57e-4: short dot products average less of the operand rounding) and the max over a CFG batch of 6 (6144 outputs)
-# lands on either side of 1e-3 depending on summation order (measured 0.95e-3 .. 1.01e-3).  Every case of the SD-v1
-# architecture -- including CFG batch 6 and t in {1, 741} -- is held to the north_star bar; the stand-in to 1.2e-3.
-TOL_BY_CFG = {'tiny': 1.2e-3, 'small40': TOL, 'sdv1': TOL}
+TOL = 1e-3            # north_star: eps of the UNet vs the reference, max-abs -- ONE bar for every configuration
+# (Round 2 carried a relaxed 1.2e-3 for the TINY stand-in because its CFG-batch-6 golden lands at 0.95e-3 .. 1.04e-3 depending
+# on the summation order.  The relaxed bar is gone: `tiny_b6_16x16` is no longer a GPU parity case -- TINY (64 model channels,
+# GroupNorm groups of 2 channels, K = 64..576 dot products) only exists to keep CPU fixtures small, its 6-row golden stays in
+# the CPU suite (tests/test_oracle_golden.py: oracle == reference), and CFG batch 6 is held to the bar on the real
+# architecture by `sdv1_b6_16x16`; rows are independent (test_batch_rows_are_independent).)
+HEADROOM_WARN = 0.9e-3      # cases above this are listed by the test below: the margin a re-tune may eat
 CFGS = {'tiny': TINY, 'small40': SMALL40, 'sdv1': SD_V1}
 _models = {}
 
@@ -45,7 +45,8 @@ def _model(cfg_name, wseed):
 # *_t1_741: t in {1, 741} (the batch-2 cases only see 981 / 481); *_b6: CFG batch 6 = txt2img's default n_samples 3
 # (scripts/txt2img.py:110-114); tiny_b10: more than 8 rows per call (n_samples 5), chunked by UNetModelHIP.forward
 CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64',
-         'sdv1_96x96', 'sdv1_t1_741_16x16', 'sdv1_b6_16x16', 'tiny_b6_16x16', 'tiny_b10_8x8']
+         'sdv1_96x96', 'sdv1_t1_741_16x16', 'sdv1_b6_16x16', 'tiny_b10_8x8']
+_measured = {}
 
 
 @pytest.mark.parametrize('case', CASES)
@@ -64,8 +65,49 @@ def test_unet_eps_matches_reference_golden(case, golden_dir):
     print(f'[unet {case}] HIP-vs-reference(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e} '
           f'|eps|max {ref.abs().max():.3f} nan={bool(torch.isnan(eps).any())}', flush=True)
     assert eps.shape == ref.shape and eps.dtype == torch.float32
-    assert float(err.max()) <= TOL_BY_CFG[cfg_name]
+    _measured[case] = float(err.max())
+    assert float(err.max()) <= TOL
     assert float(err.pow(2).mean().sqrt()) <= 2.0e-4
+
+
+def test_parity_headroom_report():
+    """The margin to the bar is thin by construction (rms 1.6e-4 with a 5-6 sigma tail); print it per case so that a change
+    of tile / split-K choices that erodes it is visible in the log before it fails."""
+    if not _measured:
+        pytest.skip('runs after the golden cases')
+    worst = max(_measured.values())
+    tight = {k: f'{v:.3e}' for k, v in sorted(_measured.items()) if v > HEADROOM_WARN}
+    print(f'[unet headroom] worst {worst:.3e} of {TOL:.0e} ({(1 - worst / TOL) * 100:.0f} % margin); above {HEADROOM_WARN:.1e}: {tight}',
+          flush=True)
+    assert worst <= TOL
+
+
+def test_parity_does_not_depend_on_the_tuning_table():
+    """The summation order of every GEMM depends on the committed (tile, split-K) table; a re-tune must not be what keeps
+    the path under the bar.  Fresh process with SDMI_TUNE_DISABLE=1 (heuristic tiles and splits everywhere): the SD-v1
+    16x16 golden still has to hold, and the two builds' eps agree to the operand-rounding noise."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import os, sys, numpy as np, torch\n"
+        f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))\n"
+        "from oracle.plan import SD_V1\n"
+        "from oracle.weights import make_inputs, make_state_dict\n"
+        "from stable_diffusion_amd import UNetModelHIP\n"
+        "z = np.load(os.path.join(sys.argv[1], 'unet_sdv1_16x16.npz'))\n"
+        "kw = SD_V1.ref_kwargs(); m = UNetModelHIP(**kw); m.load_state_dict(make_state_dict(SD_V1, int(z['weight_seed'])), strict=True)\n"
+        "m = m.cuda().eval()\n"
+        "x, t, ctx = make_inputs(SD_V1, 2, 16, 16, seed=int(z['input_seed']), ctx_len=77, timesteps=tuple(int(v) for v in z['t']))\n"
+        "eps = m(x.cuda(), t.cuda(), context=ctx.cuda()).float().cpu()\n"
+        "print('ERR', float((eps - torch.from_numpy(z['eps'])).abs().max()))\n")
+    env = dict(os.environ, SDMI_TUNE_DISABLE='1')
+    gd = os.path.join(root, 'tests', 'golden')
+    r = subprocess.run([sys.executable, '-c', code, gd], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    err = float([l for l in r.stdout.splitlines() if l.startswith('ERR')][-1].split()[1])
+    print(f'[unet sdv1_16x16, SDMI_TUNE_DISABLE=1] max-abs {err:.3e} (table: {_measured.get("sdv1_16x16", float("nan")):.3e})', flush=True)
+    assert err <= TOL
 
 
 @pytest.mark.parametrize('case', ['tiny_16x16', 'sdv1_16x16'])
@@ -115,6 +157,45 @@ def test_context_cache_and_repeatability():
     e6 = m(xc, tc, context=cc.clone())
     m.unpin_context()
     assert torch.equal(e1, e6)
+
+
+def test_pin_is_voided_by_any_displacing_forward_and_failed_calls_leave_no_hint():
+    """(1) the library has ONE K/V cache: a forward with another (B, L) -- or another context -- displaces it, so
+    the pin must be dropped whatever the shape, and the next forward of the pinned shape passes its context again instead of
+    failing on 'ctx == NULL but no cached context'; (2) a timestep hint is consumed by the call it announces even when that
+    call fails, so a later un-hinted forward computes its own timesteps."""
+    from stable_diffusion_amd._lib import SdmiError
+    m, sd = _model('tiny', 0)
+    x, t, ctx = make_inputs(TINY, 2, 16, 16, seed=5)
+    xc, tc, cc = x.cuda(), t.cuda(), ctx.cuda()
+    ref = m(xc, tc, context=cc).clone()
+    m.pin_context(cc)
+    assert torch.equal(m(xc, tc, context=cc), ref)
+    x1, t1, c1 = make_inputs(TINY, 1, 8, 8, seed=6, ctx_len=40)             # another (B, H, W, L): displaces the cache
+    m(x1.cuda(), t1.cuda(), context=c1.cuda())
+    assert m._pinned is None
+    assert torch.equal(m(xc, tc, context=cc), ref)                           # ... and the pinned shape recovers on its own
+    m.unpin_context()
+    # (2) hinted call that fails in the library (workspace of the wrong size), then an unhinted call with OTHER timesteps
+    m.cache_timesteps([981, 481])
+    other_t = torch.tensor([481, 481], device='cuda')
+    want = m(xc, other_t, context=cc).clone()
+    lib, h = m._handle.lib, m._handle.h
+    from stable_diffusion_amd import _lib as L
+    out = torch.empty_like(ref)
+    L.check(lib.sdmi_unet_hint_timestep(h, 981))
+    t981 = torch.full((2,), 981, dtype=torch.long, device='cuda')
+    small = torch.empty(1024, dtype=torch.uint8, device='cuda')
+    rc = lib.sdmi_unet_forward(h, xc.data_ptr(), t981.data_ptr(), None, cc.float().contiguous().data_ptr(), out.data_ptr(), 2, 16, 16,
+                               77, small.data_ptr(), small.numel(), L.stream_ptr())
+    assert rc != 0 and 'workspace too small' in lib.sdmi_last_error().decode()
+    got = m(xc, other_t, context=cc)
+    assert torch.equal(got, want), 'a failed hinted forward left its timestep hint behind'
+    m.cache_timesteps([])
+    # a context longer than the reserved K/V capacity is served after an explicit reservation (forward never allocates)
+    xl, tl, cl = make_inputs(TINY, 8, 8, 8, seed=8, ctx_len=96)
+    el = m(xl.cuda(), tl.cuda(), context=cl.cuda())
+    assert torch.isfinite(el).all()
 
 
 @pytest.mark.parametrize('cfg_name,B,h,w', [('tiny', 6, 16, 16), ('sdv1', 6, 16, 16), ('sdv1', 8, 8, 8), ('sdv1', 3, 32, 32)])
