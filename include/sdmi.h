@@ -218,6 +218,10 @@ typedef struct sdmi_igemm_desc {
    * epilogue; no reduce launch) and splitk_ws holds splitk * round_up(M, BM) * round_up(N, BN) floats in register order;
    * without it: slabs [splitk][M][N] and a separate reduce kernel */
   int32_t* splitk_cnt; int32_t splitk_cnt_ints;
+  /* split-fp16 dense GEMM (csrc/gemm_split16.hip; ksize 1, mode 0): a0 = high halves and a1 = low halves of the fp32
+   * activation ([M][c0] each, sdmi_k_cast_f16), w = sdmi_k_pack_split3 ([N][3 c0] = [hi | hi | lo]);
+   * out = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T from four operand tiles per 64-channel chunk.  tile: -1, 0, 1, 2, 4, 5, 8, 10 */
+  int32_t split16;
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
@@ -232,13 +236,16 @@ int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, in
                      const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,
                      void* raw_lo, float* partial_ws, int64_t partial_floats, void* stream);
 int64_t sdmi_k_groupnorm_ws_floats(int B, int HW);
-/* fused GroupNorm(32, eps) + SiLU + conv3x3 (stride 1, pad 1) over cat(x0, x1) fp32 NHWC -> out fp32 [B*H*W][N]
- * (+bias[n] +rowvec[b][n] +residual); w_packed from sdmi_k_pack_conv_weight; needs H % 8 == 0, W % 16 == 0, N % 64 == 0.
- * ResBlock in_layers / out_layers, openaimodel.py:201-204,225-231 */
+/* GroupNorm(32, eps) + SiLU folded into the staging of a 3x3 convolution (stride 1, pad 1) over cat(x0, x1) fp32 NHWC ->
+ * out fp32 [B*H*W][N] (+bias[n] +rowvec[b][n] +residual): ResBlock in_layers / out_layers, openaimodel.py:201-204,225-231.
+ * Runs the statistics kernel, then the halo-staged convolution that normalises its own input (csrc/conv3halo.hip);
+ * w_packed from sdmi_k_pack_conv_weight; power-of-two W in 8..64, (c0 + c1) / 32 >= 8; tile = -1 (auto) or a halo tile id
+ * 14..17; raw_hi / raw_lo (optional): split-fp16 copy of the raw input [B*H*W][c0 + c1]. */
 int sdmi_k_conv3gn(const float* x0, const float* x1, int c0, int c1, int B, int H, int W, const float* gamma,
                    const float* beta, float eps, const void* w_packed, int N, const float* bias, const float* rowvec,
                    int ld_rowvec, const float* residual, int ldr, float* out, int ldo, int splitk, float* splitk_ws,
-                   int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, void* stream);
+                   int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, int tile, void* raw_hi, void* raw_lo,
+                   void* stream);
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
                      void* stream);
 int sdmi_k_cast_f16(const float* x, void* out_f16, void* out_lo, int64_t n, void* stream);

@@ -42,7 +42,7 @@ class IGemmDesc(C.Structure):
                 ('segC', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', c_ptr), ('splitk_ws_floats', C.c_int64),
                 ('tile', C.c_int32), ('dma', C.c_int32), ('asym_pad', C.c_int32),
                 ('gn_n', C.c_int32), ('gn_acc', c_ptr * 2), ('gn_cpg', C.c_int32 * 2), ('gn_cbase', C.c_int32 * 2),
-                ('splitk_cnt', c_ptr), ('splitk_cnt_ints', C.c_int32)]
+                ('splitk_cnt', c_ptr), ('splitk_cnt_ints', C.c_int32), ('split16', C.c_int32)]
 
 
 _SIGS = {
@@ -98,7 +98,7 @@ _SIGS = {
     'sdmi_k_groupnorm_ws_floats': (C.c_int64, [C.c_int, C.c_int]),
     'sdmi_k_conv3gn': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, C.c_float, c_ptr,
                                  C.c_int, c_ptr, c_ptr, C.c_int, c_ptr, C.c_int, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64,
-                                 c_ptr, C.c_int64, c_ptr]),
+                                 c_ptr, C.c_int64, C.c_int, c_ptr, c_ptr, c_ptr]),
     'sdmi_k_layernorm': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr]),
     'sdmi_k_cast_f16': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_timestep_embedding': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),

@@ -253,6 +253,9 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   p.splitk_cnt = d->splitk_cnt; p.splitk_cnt_ints = d->splitk_cnt_ints;
   p.gn_n = d->gn_n;
   for (int i = 0; i < 2; ++i) { p.gn_acc[i] = (long long*)d->gn_acc[i]; p.gn_cpg[i] = d->gn_cpg[i]; p.gn_cbase[i] = d->gn_cbase[i]; }
+  if (d->split16) {                      // a0 = hi, a1 = lo (not a channel concat), w = packed [N][3K]
+    p.split16 = 1; p.c1 = 0; p.K = d->c0; p.ldw = 3 * d->c0;
+  }
   if (zero_page(&p.zero_page)) return -1;
   IGemmTune t; t.tile = d->tile; t.dma = d->dma;
   return launch_igemm(p, t, (hipStream_t)stream);
@@ -281,19 +284,25 @@ int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, in
 int sdmi_k_conv3gn(const float* x0, const float* x1, int c0, int c1, int B, int H, int W, const float* gamma,
                    const float* beta, float eps, const void* w_packed, int N, const float* bias, const float* rowvec,
                    int ld_rowvec, const float* residual, int ldr, float* out, int ldo, int splitk, float* splitk_ws,
-                   int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, void* stream) {
+                   int64_t splitk_ws_floats, float* gn_ws, int64_t gn_ws_floats, int tile, void* raw_hi, void* raw_lo,
+                   void* stream) {
   SDMI_CHECK(gn_ws_floats >= gn_acc_words(B) * 2, "groupnorm workspace too small");
   SDMI_HIP_OK(hipMemsetAsync(gn_ws, 0, gn_acc_words(B) * sizeof(long long), (hipStream_t)stream));
   GroupNormParams g;
   g.x0 = x0; g.x1 = x1; g.c0 = c0; g.c1 = c1; g.B = B; g.HW = H * W; g.gamma = gamma; g.beta = beta; g.eps = eps;
   g.stats_only = 1; g.acc = (long long*)gn_ws;
   if (launch_groupnorm(g, (hipStream_t)stream)) return -1;
-  Conv3GnParams c;
-  c.x0 = x0; c.x1 = x1; c.c0 = c0; c.c1 = c1; c.acc = (const long long*)gn_ws; c.eps = eps; c.gamma = gamma; c.beta = beta;
-  c.B = B; c.H = H; c.W = W; c.w = (const f16*)w_packed; c.N = N; c.bias = bias; c.rowvec = rowvec; c.ld_rowvec = ld_rowvec;
-  c.residual = residual; c.ldr = ldr; c.out = out; c.ldo = ldo; c.splitk = splitk; c.splitk_ws = splitk_ws;
-  c.splitk_ws_floats = splitk_ws_floats;
-  return launch_conv3gn(c, (hipStream_t)stream);
+  IGemmParams p;                       // the 3x3 convolution that normalises its own input (conv3halo.hip)
+  p.xf0 = x0; p.xf1 = x1; p.c0 = c0; p.c1 = c1; p.lda0 = c0 + c1;
+  p.gn_in_acc = (const long long*)gn_ws; p.gn_in_gamma = gamma; p.gn_in_beta = beta; p.gn_in_eps = eps; p.gn_in_silu = 1;
+  p.raw_hi = (f16*)raw_hi; p.raw_lo = (f16*)raw_lo;
+  p.B = B; p.Hin = p.Hout = H; p.Win = p.Wout = W; p.ksize = 3; p.stride = 1; p.up = 0; p.pad = 1;
+  p.w = (const f16*)w_packed; p.M = B * H * W; p.N = N; p.K = 9 * (c0 + c1);
+  p.bias = bias; p.rowvec = rowvec; p.ld_rowvec = ld_rowvec; p.residual = residual; p.ldr = ldr; p.out_f32 = out; p.ldo = ldo;
+  p.splitk = splitk; p.splitk_ws = splitk_ws; p.splitk_ws_floats = splitk_ws_floats;
+  if (zero_page(&p.zero_page)) return -1;
+  IGemmTune t; t.tile = tile;
+  return launch_igemm(p, t, (hipStream_t)stream);
 }
 int sdmi_k_layernorm(const float* x, const float* gamma, const float* beta, void* out_f16, int M, int C, float eps,
                      void* stream) {

@@ -14,6 +14,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #ifdef __HIPCC__
+// The GroupNorm(32) (+ SiLU) arithmetic of one element, shared by the stand-alone apply kernel (norm.hip) and the convolution that
+// applies it while staging its input (conv3halo.hip): one expression, written operation by operation, so both produce the same bits.
+__device__ __forceinline__ float gn_apply_elem(float v, float mean, float rstd, float gamma, float beta, int silu) {
+  float t = __builtin_fmaf((v - mean) * rstd, gamma, beta);
+  if (silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
+  return t;
+}
 // GroupNorm statistics words (see GroupNormParams::acc): add one fp32 partial / read a folded total
 __device__ __forceinline__ void gn_acc_add(unsigned long long* dst, float v) {
   const double d = (double)v;
@@ -66,9 +73,13 @@ struct IGemmParams {
   int pad = 1;                                         // 3x3 only: 1 = symmetric zero pad; 0 = pad right/bottom only (taps at +0..+2)
   const f16* w = nullptr;                              // [N][K]
   int M = 0, N = 0, K = 0;
-  // K of the reference op when the descriptor executes more (the 3-pass split-fp16 1x1 convs: K = 3 * k_alg); 0 = K.
-  // Only the profiler's algorithmic FLOP count reads it.
+  // K of the reference op when the descriptor executes more (the K-concatenated 3-pass split-fp16 1x1 convs: K = 3 * k_alg);
+  // 0 = K.  Only the profiler's algorithmic FLOP count reads it.
   int k_alg = 0;
+  // split-fp16 dense GEMM (gemm_split16.hip): a0 = high halves, a1 = low halves of the activation ([M][K], pitch lda0), w =
+  // packed [N][ldw >= 3 K] = [hi | hi | lo]; out = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T.  K = the reference op's K.
+  int split16 = 0;
+  int ldw = 0;                                         // weight row pitch (elements) of the split-fp16 GEMM
   // epilogue
   int mode = EPI_PLAIN;
   const float* bias = nullptr;                         // [N]
@@ -95,6 +106,7 @@ struct IGemmParams {
   // epilogue -- no reduce kernel.  Counters: one int per output tile, zero before the first launch (the last block resets
   // its counter).  Slabs then need splitk * round_up(M, BM) * round_up(N, BN) floats.
   int* splitk_cnt = nullptr; int splitk_cnt_ints = 0;
+  int gn_safe = 0;                                     // debugging (SDMI_GN_SAFE=1): the GroupNorm-folding conv drains the queue at every counted wait
 #ifdef SDMI_IGEMM_TIMING
   long long* dbg_times = nullptr;                      // timing build only: 6 s_memtime slots per workgroup (5 used)
   int dbg_abl = 0;                                     // timing build only (SDMI_EPI_ABL): 1 no residual loads, 2 no GroupNorm statistics, 4 no output stores
@@ -113,11 +125,25 @@ struct IGemmParams {
   // filled by the launcher: ceil(2^40 / (Hout*Wout)) and ceil(2^40 / Wout) for the kernel's division-free row split
   unsigned long long magic_hw = 0, magic_w = 0, magic_w2 = 0;   // (magic_w2: Wout + 2, halo-staged conv)
   int log2w = 0;
+  // ---- GroupNorm(32) (+ SiLU) of the INPUT folded into the halo staging (conv3halo.hip, conv3halo_gn_kernel): the A operand is
+  // then the fp32 residual stream itself (channel concat [xf0 | xf1], row pitches c0 / c1) and a0 / a1 / a2 are unused.  The
+  // statistics accumulators must be complete when the kernel starts (GroupNormParams::acc of that GroupNorm).  Optional raw_hi /
+  // raw_lo: the split-fp16 copy of the raw input ([M][c0 + c1], the operand of a ResBlock's 1x1 skip convolution), written once
+  // per pixel by the tile_n == 0 workgroups.
+  const float* xf0 = nullptr; const float* xf1 = nullptr;
+  const long long* gn_in_acc = nullptr;
+  const float* gn_in_gamma = nullptr; const float* gn_in_beta = nullptr; float gn_in_eps = 1e-5f; int gn_in_silu = 1;
+  f16* raw_hi = nullptr; f16* raw_lo = nullptr;
+  // optional fp16 [M][c0 + c1] scratch: with it the launcher may run this convolution as TWO launches instead (GroupNorm-apply
+  // kernel into the scratch, then the LDS-DMA convolution) where the tuning table measured that faster (tile id SDMI_TILE_TWO_LAUNCH)
+  f16* gn_scratch = nullptr;
+  unsigned long long magic_cpg_in = 0;                 // launcher: ceil(2^40 / ((c0 + c1) / 32))
   // halo-staged conv geometry (launcher): output rows per image in a tile, images per tile, log2(pixels per image part)
   int halo_thi = 0, halo_ipt = 1, log2_tpi = 30;
   unsigned long long magic_hpi = 0;
 };
 
+constexpr int SDMI_TILE_TWO_LAUNCH = 99;   // (tuning table, GroupNorm-folding conv keys only) GroupNorm-apply launch + LDS-DMA conv
 constexpr int SDMI_NUM_TILES = 22;   // tile ids 0 .. 21 (14..17: halo-staged 3x3 conv), see kTiles in igemm.hip and include/sdmi.h
 struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes the tuning table's choice)
   int tile = -1;          // -1 auto (tuning table, then heuristic); else a tile id
@@ -125,6 +151,9 @@ struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes
 };
 
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream);
+// may a stride-1 3x3 convolution over cat(c0, c1) fp32 channels at B x H x W fold the GroupNorm(32) of its input into its
+// staging (IGemmParams::xf0 / gn_in_*; conv3halo.hip)?
+bool gn_fold_conv_supported(int B, int H, int W, int c0, int c1, int N);
 // fp16 range guard (range.hip, debug): scan an fp16 activation buffer a launch just wrote; see SDMI_CHECK_RANGE
 bool range_check_enabled();
 int range_check_set(int enable);
@@ -139,23 +168,6 @@ int tune_end(const char* path, int* n_keys);
 int tune_dump(std::string* out);
 // out = sum_s slab[s] + bias + rowvec[batch] + residual (fixed order); uses M, N, Hout*Wout, splitk_ws, out_f32/out_f16
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
-
-// Fused GroupNorm(32) + SiLU + conv3x3 (stride 1, pad 1) over the fp32 NHWC stream (conv3gn.hip)
-struct Conv3GnParams {
-  const float* x0 = nullptr; const float* x1 = nullptr; int c0 = 0, c1 = 0;   // channel concat [x0 | x1]
-  const long long* acc = nullptr;          // statistics accumulators of the preceding GroupNorm stats launch
-  float eps = 1e-5f;
-  const float* gamma = nullptr; const float* beta = nullptr;
-  int B = 0, H = 0, W = 0;
-  const f16* w = nullptr; int N = 0;       // [N][9*Cin], chunk-major K order
-  const float* bias = nullptr; const float* rowvec = nullptr; int ld_rowvec = 0;
-  const float* residual = nullptr; int ldr = 0;
-  float* out = nullptr; int ldo = 0;
-  int splitk = 0; float* splitk_ws = nullptr; int64_t splitk_ws_floats = 0;
-  int debug = 0;     // perf ablation only (SDMI_CONV3GN_ABLATE): 1 no weight loads, 2 no MFMA work, 4 no input staging
-};
-bool conv3gn_supported(int B, int H, int W, int c0, int c1, int N);
-int launch_conv3gn(const Conv3GnParams& p, hipStream_t stream);
 
 // Flash attention over per-head layouts produced by EPI_HEADS
 struct AttnParams {
@@ -176,7 +188,7 @@ struct GroupNormParams {
   int B = 0, HW = 0;
   const float* gamma = nullptr; const float* beta = nullptr; float eps = 1e-5f;
   int silu = 0;
-  int stats_only = 0;          // 1: only compute {mean, rstd} (consumed by conv3gn via gn_stats_ptr)
+  int stats_only = 0;          // 1: only fill the statistics accumulators (consumed by a GroupNorm-folding convolution, IGemmParams::gn_in_acc)
   int skip_stats = 0;          // 1: the accumulators were already filled by the producing GEMM epilogues (IGemmParams::gn_*)
   f16* out_f16 = nullptr;      // [B*HW][C] normalised (+SiLU)
   float* out_f32 = nullptr;    // same in fp32 (used by the output head)

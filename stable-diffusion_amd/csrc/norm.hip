@@ -155,9 +155,7 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const bool second = j >= split;
-      float t = (v[u][j] - (second ? m1 : m0)) * (second ? r1 : r0) * ga[u][j] + be[u][j];
-      if (p.silu) t = t * __builtin_amdgcn_rcpf(1.0f + __expf(-t));
-      y[j] = t;
+      y[j] = gn_apply_elem(v[u][j], second ? m1 : m0, second ? r1 : r0, ga[u][j], be[u][j], p.silu);
     }
     const size_t o = pix[u] * C + c;
     if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};

@@ -45,7 +45,6 @@ int UNet::build(const sdmi_unet_cfg& c) {
   const int mc = c.model_channels;
   te_ = 4 * mc;
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
-  if (const char* e = getenv("SDMI_FUSE_GN_CONV")) fuse_gn_conv_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_FUSE_GN_STATS")) fuse_gn_stats_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_SIDE_STREAM")) side_stream_ = atoi(e) != 0;
   const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
@@ -431,14 +430,20 @@ struct Fwd : FwdBase {
   int emb_ld = 0;
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
 
-  void gn_stats_only(const Act& x0, const Act* x1, float eps, f16* raw, f16* raw_lo, const float* gamma, const float* beta) {
-    GroupNormParams g;
-    g.x0 = x0.p; g.c0 = x0.C;
-    if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
-    g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = 0;
-    g.raw_f16 = raw; g.raw_lo = raw_lo; g.stats_only = (raw == nullptr && raw_lo == nullptr);
-    g.acc = next_gn_acc();
-    if (!dry && !rc) ok(launch_groupnorm(g, s));
+  // conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) with the normalisation folded into the convolution's halo staging
+  // (openaimodel.py:201-204,225-231): statistics first (from the producers' epilogues when the plan has them), then ONE launch
+  IGemmParams conv3_gn(const Act& x0, const Act* x1, const float* gamma, const float* beta, const f16* w, int N, f16* raw_hi,
+                       f16* raw_lo) {
+    long long* acc = groupnorm(x0, x1, gamma, beta, 1e-5f, 1, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
+    const int Cin = x0.C + (x1 ? x1->C : 0);
+    IGemmParams p = conv3(nullptr, Cin, x0.H, x0.W, x0.H, x0.W, 1, 0, w, N);
+    p.xf0 = x0.p; p.c0 = x0.C; p.xf1 = x1 ? x1->p : nullptr; p.c1 = x1 ? x1->C : 0; p.lda0 = Cin;
+    p.gn_in_acc = acc; p.gn_in_gamma = gamma; p.gn_in_beta = beta; p.gn_in_eps = 1e-5f; p.gn_in_silu = 1;
+    p.raw_hi = raw_hi; p.raw_lo = raw_lo;
+    // (scratch for the launcher's two-launch alternative: per shape, the tuning table decides between the folding kernel and
+    // GroupNorm-apply + LDS-DMA conv -- same operand bits either way)
+    p.gn_scratch = S<f16>((size_t)B * x0.H * x0.W * Cin);
+    return p;
   }
 
   Act res_block(Layer& L, const Act& x0, const Act* x1) {
@@ -447,51 +452,50 @@ struct Fwd : FwdBase {
     if (Cin != L.cin) { ok(fail("res block channel mismatch at " + L.prefix)); }
     if (Cin == Cout && x1) ok(fail("identity skip with a concatenated input at " + L.prefix));
     const size_t mark = scratch.off;
-    // high-resolution levels: GroupNorm + SiLU fused into the halo-staged 3x3 conv (conv3gn.hip)
-    const bool fused = u->fuse_gn_conv_ && H * W >= 1024 && conv3gn_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout) &&
-                       conv3gn_supported(B, H, W, Cout, 0, Cout);
+    // GroupNorm + SiLU folded into the halo staging of the 3x3 convs where the geometry allows (every level of SD v1)
+    // (SDMI_FUSE_GN_WHICH: bit 0 in_layers, bit 1 out_layers; SDMI_FUSE_GN_W: only at this width -- bisecting knobs)
+    static const int fold_which = getenv("SDMI_FUSE_GN_WHICH") ? atoi(getenv("SDMI_FUSE_GN_WHICH")) : 3;
+    static const int fold_w = getenv("SDMI_FUSE_GN_W") ? atoi(getenv("SDMI_FUSE_GN_W")) : 0;
+    const bool fold_here = fold_w == 0 || fold_w == W;
+    const bool fold1 = (fold_which & 1) && fold_here && gn_fold_conv_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
+    const bool fold2 = (fold_which & 2) && fold_here && gn_fold_conv_supported(B, H, W, Cout, 0, Cout);
     f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
     f16* raw_lo = (Cin != Cout && precise_1x1) ? S<f16>((size_t)M * Cin) : nullptr;
     float* h = S<float>((size_t)M * Cout);
-    Act out = make_act(P<float>((size_t)M * Cout), Cout, H, W, !fused);
-    Act hact = make_act(h, Cout, H, W, !fused);
-    if (fused) {
-      gn_stats_only(x0, x1, 1e-5f, raw, raw_lo, L.f32[0], L.f32[1]);
-      Conv3GnParams c;
-      c.x0 = x0.p; c.c0 = x0.C; if (x1) { c.x1 = x1->p; c.c1 = x1->C; }
-      c.acc = last_gn_acc(); c.eps = 1e-5f; c.gamma = L.f32[0]; c.beta = L.f32[1]; c.B = B; c.H = H; c.W = W;
-      c.w = L.w16[0]; c.N = Cout; c.bias = L.f32[2]; c.rowvec = emb_all + L.emb_off; c.ld_rowvec = emb_ld;
-      c.out = h; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
-      if (!dry && !rc) ok(launch_conv3gn(c, s));
-    } else {
-      f16* a = S<f16>((size_t)M * Cin);
-      groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
-      if (Cin != Cout) fork_side();
-      IGemmParams p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
+    Act out = make_act(P<float>((size_t)M * Cout), Cout, H, W, true);
+    Act hact = make_act(h, Cout, H, W, true);
+    {
+      IGemmParams p;
+      if (fold1) {
+        p = conv3_gn(x0, x1, L.f32[0], L.f32[1], L.w16[0], Cout, raw, raw_lo);    // (+ the skip conv's raw hi | lo operand)
+      } else {
+        f16* a = S<f16>((size_t)M * Cin);
+        groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
+        p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
+      }
+      if (Cin != Cout && !fold1) fork_side();
       p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = emb_ld;
       p.out_f32 = h; p.ldo = Cout;
       attach_gn_targets(p, hact);          // statistics of out_layers' GroupNorm come out of this epilogue
       gemm(p);
     }
     const float* residual = x0.p;
-    if (Cin != Cout) {       // skip_connection: needs only the raw fp16 copies GroupNorm 1 wrote; joined before conv2's epilogue reads it
+    if (Cin != Cout) {       // skip_connection: needs only the raw fp16 copies (written by GroupNorm 1 / by conv1's staging)
       IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W);
       p.bias = L.f32[6]; p.out_f32 = out.p; p.ldo = Cout;
-      if (fused) gemm(p); else gemm_side(p);
+      if (fold1) gemm(p); else gemm_side(p);
       residual = out.p;
     }
-    if (fused) {
-      gn_stats_only(hact, nullptr, 1e-5f, nullptr, nullptr, L.f32[3], L.f32[4]);
-      Conv3GnParams c;
-      c.x0 = h; c.c0 = Cout; c.acc = last_gn_acc(); c.eps = 1e-5f; c.gamma = L.f32[3]; c.beta = L.f32[4]; c.B = B; c.H = H; c.W = W;
-      c.w = L.w16[1]; c.N = Cout; c.bias = L.f32[5]; c.residual = residual; c.ldr = Cout;
-      c.out = out.p; c.ldo = Cout; c.splitk = 0; c.splitk_ws = splitk_ws; c.splitk_ws_floats = splitk_ws_floats;
-      if (!dry && !rc) ok(launch_conv3gn(c, s));
-    } else {
-      f16* a2 = S<f16>((size_t)M * Cout);
-      groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
-      if (Cin != Cout) join_side();
-      IGemmParams p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
+    {
+      IGemmParams p;
+      if (fold2) {
+        p = conv3_gn(hact, nullptr, L.f32[3], L.f32[4], L.w16[1], Cout, nullptr, nullptr);
+      } else {
+        f16* a2 = S<f16>((size_t)M * Cout);
+        groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
+        p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
+      }
+      if (Cin != Cout && !fold1) join_side();
       p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
       attach_gn_targets(p, out);           // ... and those of the GroupNorm(s) that read this block's output
       attach_f16_copy(p, out);             // ... and the fp16 copy a Downsample / Upsample behind this block wants

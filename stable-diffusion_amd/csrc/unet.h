@@ -1,5 +1,7 @@
 // UNet executor state (see unet.cpp).
 #pragma once
+#include <stdlib.h>
+
 #include <map>
 #include <string>
 #include <utility>
@@ -171,21 +173,32 @@ struct FwdBase {
     p.ksize = 3; p.stride = stride; p.up = up; p.w = w; p.M = B * Hout * Wout; p.N = N; p.K = 9 * C; p.splitk = 0;
     return p;
   }
-  // 1x1 conv on split-fp16 operands: A' = [hi | lo | hi], W' = [hi | hi | lo] (packed W_SPLIT3) when precise
+  // 1x1 conv on split-fp16 operands (packed W_SPLIT3 weights [N][3K] = [hi | hi | lo]) when precise: the split-fp16 GEMM family
+  // (gemm_split16.hip: four operand tiles per 64-channel chunk, three MFMAs per fragment pair); SDMI_SPLIT16_KERNEL=0 = the
+  // rounds-1/2 formulation, one K-concatenated GEMM A' = [hi | lo | hi] through the generic kernel (A/B)
   IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch) {
     IGemmParams p = dense(hi, M, K, w, N, rows_per_batch);
     if (precise_1x1) {
-      p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K; p.k_alg = K;
+      static const bool family = !(getenv("SDMI_SPLIT16_KERNEL") && atoi(getenv("SDMI_SPLIT16_KERNEL")) == 0);
+      if (family && K % 64 == 0) {
+        p.a1 = lo; p.lda1 = K; p.split16 = 1; p.ldw = 3 * K;
+      } else {
+        p.a1 = lo; p.c1 = K; p.lda1 = K; p.a2 = hi; p.c2 = K; p.lda2 = K; p.K = 3 * K; p.k_alg = K;
+      }
     }
     return p;
   }
-  void groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
-                 float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr) {
+  // stats_only: fill (or, when the producers' epilogues did, just locate) the statistics accumulators of this GroupNorm and
+  // launch no apply kernel -- the consuming convolution normalises while it stages its input (IGemmParams::gn_in_acc).
+  // Returns the accumulator region.
+  long long* groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
+                       float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr, bool stats_only = false) {
     GroupNormParams g;
     g.x0 = x0.p; g.c0 = x0.C;
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
     g.B = B; g.HW = x0.H * x0.W; g.gamma = gamma; g.beta = beta; g.eps = eps; g.silu = silu;
     g.out_f16 = o16; g.out_f32 = o32; g.raw_f16 = raw; g.out_lo = o16_lo; g.raw_lo = raw_lo;
+    g.stats_only = stats_only ? 1 : 0;
     const int idx = gn_calls;
     g.acc = next_gn_acc();
     if (plan) {
@@ -203,7 +216,8 @@ struct FwdBase {
         g.skip_stats = (idx < (int)plan->fused.size() && plan->fused[idx]) ? 1 : 0;
       }
     }
-    if (!dry && !rc) ok(launch_groupnorm(g, s));
+    if (!dry && !rc && !(stats_only && g.skip_stats)) ok(launch_groupnorm(g, s));
+    return g.acc;
   }
 };
 
@@ -280,10 +294,8 @@ class UNet {
   // 1x1 convs on the residual stream (skip_connection, proj_in, proj_out) run as 3-pass split-fp16 GEMMs
   // (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): ~22-bit operands for 5 % of the FLOPs (DESIGN.md "precision")
   bool precise_1x1_ = true;
-  // opt-in (SDMI_FUSE_GN_CONV=1): ResBlock convs at >= 32x32 as fused GroupNorm+SiLU+conv3x3 with halo-staged input
-  // tiles (conv3gn.hip).  Same-box A/B: the fused path is 0.7 ms / UNet call SLOWER than GroupNorm + igemm
-  // (8.89 vs 8.18 ms, profiles/ab_conv3gn_reduce_ln_r01.txt), so it is off by default.
-  bool fuse_gn_conv_ = false;
+  // ResBlock convs fold the GroupNorm + SiLU of their input into their halo staging (conv3halo.hip, conv3halo_gn_kernel) wherever
+  // gn_fold_conv_supported() says so; SDMI_FUSE_GN_CONV=0 restores the GroupNorm-apply launches (A/B).
 
  private:
   friend struct Fwd;

@@ -43,7 +43,7 @@ def cast_f16(x, want_lo=False):
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
           residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None, fused_splitk=True,
-          asym_pad=0, gn=None):
+          asym_pad=0, gn=None, split16=False):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
     d = _lib.IGemmDesc()
     d.a0 = a0.data_ptr(); d.c0 = a0.shape[1]; d.lda0 = a0.stride(0)
@@ -67,6 +67,7 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
         d.heads, d.dh, d.ntok, d.ntok_pad, d.segC = heads['heads'], heads['dh'], heads['ntok'], heads['ntok_pad'], heads['segC']
     d.splitk, d.tile, d.dma = splitk, tile, dma
     d.asym_pad = asym_pad
+    d.split16 = 1 if split16 else 0      # a0 = hi, a1 = lo, w = pack_split3 ([N][3 c0])
     if gn:      # [(acc int64 tensor [B,32,8,16] (zeroed), cpg, cbase)]
         d.gn_n = len(gn)
         for i, (acc, cpg, cbase) in enumerate(gn):
@@ -220,8 +221,9 @@ def report(name, got, ref, tol):
     return mx
 
 
-def conv3gn(x0, x1, gamma, beta, eps, w, bias=None, rowvec=None, residual=None, splitk=0):
-    """x0/x1: fp32 [B, H, W, C]; w: OIHW fp32 -> out fp32 [B*H*W, N]"""
+def conv3gn(x0, x1, gamma, beta, eps, w, bias=None, rowvec=None, residual=None, splitk=0, tile=-1, want_raw=False):
+    """GroupNorm + SiLU folded into the halo-staged 3x3 conv.  x0/x1: fp32 [B, H, W, C]; w: OIHW fp32 -> out fp32 [B*H*W, N]
+    (and, with want_raw, the split-fp16 copy (hi, lo) of cat(x0, x1))"""
     B, H, W, c0 = x0.shape
     c1 = 0 if x1 is None else x1.shape[3]
     N = w.shape[0]
@@ -231,9 +233,11 @@ def conv3gn(x0, x1, gamma, beta, eps, w, bias=None, rowvec=None, residual=None, 
     n = _lib.load().sdmi_k_groupnorm_ws_floats(B, H * W)
     gws = torch.empty((n,), dtype=torch.float32, device=dev)
     ws = torch.empty((16 * B * H * W * N,), dtype=torch.float32, device=dev)
+    rhi = torch.full((B * H * W, c0 + c1), float('nan'), dtype=torch.float16, device=dev) if want_raw else None
+    rlo = torch.full((B * H * W, c0 + c1), float('nan'), dtype=torch.float16, device=dev) if want_raw else None
     _lib.check(_lib.load().sdmi_k_conv3gn(
         x0.data_ptr(), _lib.ptr(x1), c0, c1, B, H, W, gamma.data_ptr(), beta.data_ptr(), float(eps), wp.data_ptr(), N,
         _lib.ptr(bias), _lib.ptr(rowvec), 0 if rowvec is None else rowvec.stride(0), _lib.ptr(residual),
         0 if residual is None else residual.stride(0), out.data_ptr(), N, splitk, ws.data_ptr(), ws.numel(),
-        gws.data_ptr(), n, _s()))
-    return out
+        gws.data_ptr(), n, tile, _lib.ptr(rhi), _lib.ptr(rlo), _s()))
+    return (out, rhi, rlo) if want_raw else out

@@ -264,6 +264,36 @@ def test_igemm_split_fp16_1x1():
     assert err3 < 2e-5 and err3 < err1 / 20
 
 
+@pytest.mark.parametrize('tile', [-1, 0, 1, 2, 4, 5, 8, 10])
+@pytest.mark.parametrize('M,Kd,N,splitk', [(300, 320, 192, 1), (2048, 640, 640, 1), (512, 1280, 328, 4), (128, 1920, 1280, 6), (70, 64, 40, 1)])
+def test_gemm_split16(tile, M, Kd, N, splitk):
+    """split-fp16 dense GEMM family (gemm_split16.hip): a_hi w_hi + a_lo w_hi + a_hi w_lo from four operand tiles per 64-channel
+    chunk -- fp32 operands to ~2^-22 -- against the fp64 product, against the K-concatenated formulation it replaces (same
+    products, another summation order), with bias + residual, M / N tails and split-K; two runs are bit-identical."""
+    g = _g(M + Kd + N)
+    x = torch.randn(M, Kd, generator=g) * 2.0
+    w = torch.randn(N, Kd, generator=g) / math.sqrt(Kd)
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref = (x.double() @ w.double().t()).float() + bias[None] + resid
+    hi, lo = K.cast_f16(x.to(DEV), want_lo=True)
+    wp = K.pack_split3(w.to(DEV))
+    out = torch.full((M, N), float('nan'), device=DEV)
+    K.igemm(hi, wp, N, 1, M, 1, M, 1, a1=lo, bias=bias.to(DEV), residual=resid.to(DEV), out_f32=out, split16=True, tile=tile,
+            splitk=splitk, fused_splitk=False)
+    torch.cuda.synchronize()
+    err = K.report(f'gemm_split16 M{M} K{Kd} N{N} tile{tile} k{splitk}', out, ref, 3e-5)
+    old = torch.full((M, N), float('nan'), device=DEV)
+    K.igemm(hi, wp, N, 1, M, 1, M, 1, a1=lo, a2=hi, bias=bias.to(DEV), residual=resid.to(DEV), out_f32=old)
+    err_old = K.report('   ... K-concatenated formulation', old, ref, 3e-5)
+    assert err < 3e-5 and err <= 2.0 * err_old + 2e-6
+    out2 = torch.full((M, N), float('nan'), device=DEV)
+    K.igemm(hi, wp, N, 1, M, 1, M, 1, a1=lo, bias=bias.to(DEV), residual=resid.to(DEV), out_f32=out2, split16=True, tile=tile,
+            splitk=splitk, fused_splitk=False)
+    torch.cuda.synchronize()
+    assert torch.equal(out, out2)
+
+
 def test_igemm_geglu():
     """FeedForward/GEGLU, attention.py:37-64: value = first half, gate = second half, exact erf GELU."""
     g = _g(6)
@@ -665,12 +695,35 @@ def test_sampler_step_bit_exact(mode, cfg):
     assert torch.equal(x_o.cpu(), xp), 'x_prev not bit-exact'
 
 
-@pytest.mark.parametrize('B,H,W,c0,c1,N,splitk', [(2, 8, 16, 64, 0, 64, 1), (2, 16, 32, 128, 64, 128, 0), (1, 32, 32, 320, 0, 320, 1),
-                                                  (2, 64, 64, 320, 0, 320, 0), (2, 32, 32, 640, 320, 640, 2), (1, 8, 16, 192, 0, 64, 3)])
-def test_conv3gn_fused(B, H, W, c0, c1, N, splitk):
-    """ResBlock in_layers / out_layers: conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) + bias + emb + residual
-    (openaimodel.py:201-204,225-231,263-275) as one fused kernel with halo-staged input tiles."""
-    g = _g(B * H + c0 + N)
+# ---- GroupNorm + SiLU folded into the halo staging of the 3x3 convolution (csrc/conv3halo.hip, conv3halo_gn_kernel) ---------------
+GN_FOLD_CASES = [
+    # name, B, H, W, c0, c1, N, splitk, tile  (at least 8 channels per group: c0 + c1 >= 256)
+    ('l0_w64_t14', 2, 64, 64, 320, 0, 64, 1, 14),
+    ('l0_w64_t15', 1, 64, 64, 256, 0, 128, 2, 15),
+    ('l0_w64_t16_cat', 1, 64, 64, 192, 128, 64, 1, 16),       # two fp32 sources with different row pitches
+    ('l1_w32_t14_cat', 2, 32, 32, 640, 320, 128, 3, 14),
+    ('l1_w32_t17', 2, 32, 32, 320, 0, 128, 1, 17),
+    ('l2_w16_t14', 2, 16, 16, 1280, 0, 128, 5, 14),           # one whole 16x16 image per 256-row tile
+    ('l2_w16_t16', 2, 16, 16, 640, 0, 64, 2, 16),
+    ('l3_w8_t16', 2, 8, 8, 1280, 0, 128, 10, 16),             # two whole 8x8 images per 128-row tile
+    ('l3_w8_t14_b4', 4, 8, 8, 640, 640, 64, 4, 14),           # four whole images per 256-row tile
+    ('auto', 2, 32, 32, 640, 0, 640, 0, -1),                  # tile and split chosen by the launcher
+    # a workgroup's chunk range crossing from the first fp32 source into the second, small channel counts (the TINY / SMALL40
+    # configurations' output blocks), every tile at W = 64
+    ('l0_w64_t16', 1, 64, 64, 320, 0, 64, 1, 16),
+    ('l0_w64_t14_cat', 1, 64, 64, 192, 128, 64, 1, 14),
+    ('l0_w64_t17_cat', 1, 64, 64, 192, 128, 128, 1, 17),
+    ('l1_w32_t16_cat', 1, 32, 32, 192, 128, 64, 1, 16),
+    ('l1_w32_t14_cat_cross', 2, 32, 32, 640, 320, 128, 1, 14),
+    ('tiny_w16_t14_cat', 2, 16, 16, 128, 128, 128, 2, 14),
+    ('tiny_w16_t14_cat_k1', 2, 16, 16, 128, 128, 128, 1, 14),
+    ('tiny_w8_t16_cat', 2, 8, 8, 128, 128, 64, 1, 16),
+    ('tiny_w8_t16_cat_k2', 2, 8, 8, 128, 128, 64, 2, 16),
+]
+
+
+def _gn_fold_inputs(B, H, W, c0, c1, N, seed):
+    g = _g(seed)
     C = c0 + c1
     x0 = torch.randn(B, H, W, c0, generator=g) * 1.3 + 0.2
     x1 = torch.randn(B, H, W, c1, generator=g) * 0.8 - 0.1 if c1 else None
@@ -680,16 +733,39 @@ def test_conv3gn_fused(B, H, W, c0, c1, N, splitk):
     bias = torch.randn(N, generator=g) * 0.1
     rowvec = torch.randn(B, N, generator=g)
     resid = torch.randn(B * H * W, N, generator=g)
+    return x0, x1, gamma, beta, w, bias, rowvec, resid
+
+
+@pytest.mark.parametrize('case', GN_FOLD_CASES, ids=[c[0] for c in GN_FOLD_CASES])
+def test_conv3_gn_fold(case):
+    """ResBlock in_layers / out_layers: conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) + bias + emb + residual
+    (openaimodel.py:201-204,225-231,263-275) as ONE launch that normalises its input while staging it: against the fp32 torch
+    ops, and BIT FOR BIT against the two-launch path it replaces (GroupNorm-apply kernel -> LDS-DMA halo conv, same tile)."""
+    name, B, H, W, c0, c1, N, splitk, tile = case
+    x0, x1, gamma, beta, w, bias, rowvec, resid = _gn_fold_inputs(B, H, W, c0, c1, N, B * H + c0 + N)
+    C = c0 + c1
     x = x0 if x1 is None else torch.cat([x0, x1], dim=3)
     xn = F.silu(F.group_norm(x.permute(0, 3, 1, 2), 32, gamma, beta, 1e-5))
     # the kernel rounds the normalised activation and the weights to fp16 once (MFMA operands), accumulates in fp32
     ref = F.conv2d(xn.half().float(), w.half().float(), None, padding=1)
     ref = _nhwc(ref) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
-    out = K.conv3gn(x0.to(DEV), None if x1 is None else x1.to(DEV), gamma.to(DEV), beta.to(DEV), 1e-5, w.to(DEV),
-                    bias=bias.to(DEV), rowvec=rowvec.to(DEV), residual=resid.to(DEV), splitk=splitk)
+    d = lambda t: None if t is None else t.to(DEV)
+    out, rhi, rlo = K.conv3gn(d(x0), d(x1), d(gamma), d(beta), 1e-5, d(w), bias=d(bias), rowvec=d(rowvec), residual=d(resid),
+                              splitk=splitk, tile=tile, want_raw=True)
     torch.cuda.synchronize()
-    # vs the fp16-operand reference: the only differences are fp32 GN rounding flips of fp16 operands (<= 1 fp16 ulp on a
-    # handful of A elements) and accumulation order
-    assert K.report(f'conv3gn B{B} {H}x{W} {c0}+{c1}->{N} k{splitk}', out, ref, 3e-3) < 3e-3
-    exact = _nhwc(F.conv2d(xn, w, None, padding=1)) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
-    K.report('   ... vs exact fp32 conv', out, exact, 2e-2)
+    # vs the fp16-operand reference: fp32 GN rounding flips of fp16 operands (<= 1 fp16 ulp on a handful of A elements) and
+    # accumulation order
+    assert K.report(f'conv3 gn-fold {name}', out, ref, 3e-3) < 3e-3
+    # the raw split-fp16 copy (operand of the ResBlock's 1x1 skip conv): exactly the cast kernel's values, every pixel once
+    xc = x.reshape(B * H * W, C).to(DEV)
+    hi, lo = K.cast_f16(xc, want_lo=True)
+    assert torch.equal(rhi, hi) and torch.equal(rlo, lo)
+    if tile >= 0:
+        # the path it replaces, same tile and split: identical fp16 operand -> identical MFMA sequence -> identical bits
+        gn = K.groupnorm(d(x0).reshape(B, H * W, c0), None if x1 is None else d(x1).reshape(B, H * W, c1), d(gamma), d(beta), 1e-5, 1,
+                         want=('f16',))
+        out2 = torch.full((B * H * W, N), float('nan'), device=DEV)
+        K.igemm(gn['f16'].reshape(B * H * W, C), K.pack_conv_weight(d(w)), N, B, H, W, H, W, ksize=3, bias=d(bias), rowvec=d(rowvec),
+                residual=d(resid), out_f32=out2, splitk=splitk, tile=tile, fused_splitk=False)
+        torch.cuda.synchronize()
+        assert torch.equal(out, out2), float((out - out2).abs().max())
