@@ -371,6 +371,12 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_gn_kernel(con
 
   const int tid = threadIdx.x;
   SDMI_STAMP(dbg_t0);
+#ifdef SDMI_GN_POISON
+  // bisecting build: the whole LDS starts as fp16 NaNs -- a fragment read that runs ahead of its tile produces NaNs instead of
+  // whatever the previous kernel on this CU left there (in a repeated test: the same tile)
+  for (int e = tid; e < LDS_BYTES / 16; e += NT) *(u32x4*)(smem + e * 16) = u32x4{0x7e007e00u, 0x7e007e00u, 0x7e007e00u, 0x7e007e00u};
+  __syncthreads();
+#endif
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int cpos = tid & 7, lrow = tid >> 3;
@@ -461,8 +467,24 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_gn_kernel(con
   f32x4 st[NSLOT][2];
   f32x4 gam[2], bet[2];
   auto ld32 = [&](f32x4& lo, f32x4& hi, const i32x4& desc, int voff) {
+#ifdef SDMI_GN_VISIBLE
+    // bisecting build (-DSDMI_GN_VISIBLE): loads the compiler can see -- it waits for them itself (and drains the DMA ring doing so)
+    const unsigned long long a = (unsigned long long)(unsigned)desc[0] | ((unsigned long long)((unsigned)desc[1] & 0xffffu) << 32);
+    const bool in = (unsigned)voff < (unsigned)desc[2];
+    const f32x4* src = (const f32x4*)((const char*)a + (in ? voff : 0));
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    lo = in ? __builtin_nontemporal_load(src) : z; hi = in ? __builtin_nontemporal_load(src + 1) : z;
+#elif defined(SDMI_GN_POISON)
+    // bisecting build (-DSDMI_GN_POISON): the destination registers hold NaNs until the load lands -- a conversion that runs ahead
+    // of its data produces NaNs instead of whatever the registers held before (in a repeated test: the same data)
+    const float qn = __builtin_nanf("");
+    lo = f32x4{qn, qn, qn, qn}; hi = lo;
+    asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16"
+                 : "+&v"(lo), "+&v"(hi) : "v"(voff), "s"(desc) : "memory");
+#else
     asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %2, %3, 0 offen\n\tbuffer_load_dwordx4 %1, %2, %3, 0 offen offset:16"
                  : "=&v"(lo), "=&v"(hi) : "v"(voff), "s"(desc) : "memory");
+#endif
   };
   auto load_piece = [&](const ChunkSrc& cs, int q) {
     const int voff = hpix[q] >= 0 ? (hpix[q] * cs.ld + cs.coff + cpos * 8) * 4 : OOB;
@@ -630,6 +652,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_gn_kernel(con
             if (gn_safe) wait_vmcnt<0>();
             tie_piece(qc, Sched::LT(qc) == 0);
             store_piece(csn, hb ^ 1, qc, st[qc % NSLOT][0], st[qc % NSLOT][1]);
+#ifdef SDMI_GN_XBAR
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");      // bisecting build: a full barrier behind every conversion
+#endif
           }
         });
       } else {
@@ -805,7 +830,12 @@ int launch_halo_gn_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
 }
 
 bool gn_fold_conv_supported(int B, int H, int W, int c0, int c1, int N) {
-  static const int env_on = env_int("SDMI_FUSE_GN_CONV", 1);           // 0: GroupNorm-apply launches + LDS-DMA convolutions everywhere (A/B)
+  // Opt-in (SDMI_FUSE_GN_CONV=1).  Same-box A/B, round 3 (profiles/gn_fold_r03.txt): 6.97 ms per UNet call with the folding kernel
+  // at its heuristic sites, 8.04 ms with it at every site, against 6.50 ms for GroupNorm-apply launches + the tuned LDS-DMA
+  // convolutions: every one of the N / BN column tiles of a convolution repeats the normalisation (+ SiLU: two quarter-rate
+  // transcendentals per element) of its input halo, 5 ... 20 times the work of the stand-alone kernel, and reads the stream as
+  // fp32 through registers instead of fp16 by DMA.
+  static const int env_on = env_int("SDMI_FUSE_GN_CONV", 0);
   if (!env_on) return false;
   IGemmParams p;
   p.B = B; p.Hin = p.Hout = H; p.Win = p.Wout = W; p.ksize = 3; p.stride = 1; p.pad = 1; p.up = 0;

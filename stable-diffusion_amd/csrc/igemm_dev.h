@@ -178,18 +178,33 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
       for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    for (int s = 0; s < p.splitk; ++s) {
-      const int off = (s * (BM * BN) + tid * 4) * 4;
+    // The slab reads are memory-side round trips (~2 us each way): SB splits' worth of them are requested back to back (up to 16
+    // quads = 64 VGPRs in flight) and only then added, still in split order -- one round trip per batch instead of one per split
+    // (the first version of this loop waited per split: +28 us on a 12-way split, profiles/splitk_fused_r02.txt).
+    constexpr int QPS = TM * TN * 4;                       // 16-byte quads of one split's slab per lane
+    constexpr int SB = QPS >= 16 ? 1 : 16 / QPS;           // splits per batch
+    for (int s0 = 0; s0 < p.splitk; s0 += SB) {
+      f32x4 v[SB][QPS];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
+      for (int ss = 0; ss < SB; ++ss) {
+        const int off = (min(s0 + ss, p.splitk - 1) * (BM * BN) + tid * 4) * 4;     // (past the last split: a repeat that is not added)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
+        for (int e = 0; e < QPS; ++e)
+          v[ss][e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, off + e * (NT * 16), 0, SC1));
+      }
 #pragma unroll
-          for (int r4 = 0; r4 < 4; ++r4) {
-            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ws, off + ((i * TN + j) * 4 + r4) * (NT * 16), 0, SC1));
+      for (int ss = 0; ss < SB; ++ss) {
+        if (s0 + ss < p.splitk) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[e];
-          }
+          for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+              for (int r4 = 0; r4 < 4; ++r4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[i][j][4 * r4 + e] += v[ss][(i * TN + j) * 4 + r4][e];
+        }
+      }
     }
     __syncthreads();                       // smem[0] is reused below
   }
