@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 9
+#define SDMI_ABI_VERSION 10
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -222,8 +222,19 @@ typedef struct sdmi_igemm_desc {
    * activation ([M][c0] each, sdmi_k_cast_f16), w = sdmi_k_pack_split3 ([N][3 c0] = [hi | hi | lo]);
    * out = a_hi w_hi^T + a_lo w_hi^T + a_hi w_lo^T from four operand tiles per 64-channel chunk.  tile: -1, 0, 1, 2, 4, 5, 8, 10 */
   int32_t split16;
+  /* LayerNorm folded into the consuming GEMM (attention.py:211-215; csrc/common.h IGemmParams::lnp_out / lnf_*).
+   * Producer (mode 0, out_f32 and out_f16, no split-K): out_f16 = fp16(f16_scale[n] * v) and lnp_out[(n / 32) * M + m] =
+   * float2{sum, sum of squares} of row m over each 32-column block.  Consumer (dense, one source, no bias, no split-K): a0 =
+   * that operand, lnf_part = its partials (lnf_npart = K / 32); every accumulator becomes
+   * rstd_m * (acc - mean_m * lnf_cs[n]) + lnf_d[n] (vectors from sdmi_k_ln_fold_prep) before the mode's epilogue. */
+  const float* f16_scale; float* lnp_out;
+  const float* lnf_part; int32_t lnf_npart; float lnf_eps; const float* lnf_cs; const float* lnf_d;
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
+/* cs[n] = sum_k gamma[k] * w[n][k], d[n] = sum_k beta[k] * w[n][k] (+ bias[n]) over the PACKED fp16 weights w [N][ldw]
+ * (first K columns of a row): the column terms of a GEMM that folds LayerNorm(gamma, beta) of its input rows */
+int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,
+                        float* cs, float* d, void* stream);
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
 int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
                      int nkv_pad, int d, float scale, void* stream);

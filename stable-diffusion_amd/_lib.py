@@ -42,7 +42,9 @@ class IGemmDesc(C.Structure):
                 ('segC', C.c_int32), ('splitk', C.c_int32), ('splitk_ws', c_ptr), ('splitk_ws_floats', C.c_int64),
                 ('tile', C.c_int32), ('dma', C.c_int32), ('asym_pad', C.c_int32),
                 ('gn_n', C.c_int32), ('gn_acc', c_ptr * 2), ('gn_cpg', C.c_int32 * 2), ('gn_cbase', C.c_int32 * 2),
-                ('splitk_cnt', c_ptr), ('splitk_cnt_ints', C.c_int32), ('split16', C.c_int32)]
+                ('splitk_cnt', c_ptr), ('splitk_cnt_ints', C.c_int32), ('split16', C.c_int32),
+                ('f16_scale', c_ptr), ('lnp_out', c_ptr), ('lnf_part', c_ptr), ('lnf_npart', C.c_int32),
+                ('lnf_eps', C.c_float), ('lnf_cs', c_ptr), ('lnf_d', c_ptr)]
 
 
 _SIGS = {
@@ -110,6 +112,7 @@ _SIGS = {
     'sdmi_k_pack_conv_out': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_split3': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_geglu': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
+    'sdmi_k_ln_fold_prep': (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sdmi_image_to_uint8': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_range_check': (C.c_int, [C.c_int]),
     'sdmi_range_report': (C.c_int, [C.c_char_p, C.c_int]),
@@ -142,7 +145,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 9:
+        if lib.sdmi_abi_version() != 10:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -256,9 +256,15 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   if (d->split16) {                      // a0 = hi, a1 = lo (not a channel concat), w = packed [N][3K]
     p.split16 = 1; p.c1 = 0; p.K = d->c0; p.ldw = 3 * d->c0;
   }
+  p.f16_scale = d->f16_scale; p.lnp_out = d->lnp_out;
+  p.lnf_part = d->lnf_part; p.lnf_npart = d->lnf_npart; p.lnf_eps = d->lnf_eps; p.lnf_cs = d->lnf_cs; p.lnf_d = d->lnf_d;
   if (zero_page(&p.zero_page)) return -1;
   IGemmTune t; t.tile = d->tile; t.dma = d->dma;
   return launch_igemm(p, t, (hipStream_t)stream);
+}
+int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,
+                        float* cs, float* d, void* stream) {
+  return launch_ln_fold_prep((const f16*)w_f16, N, K, ldw, gamma, beta, bias, cs, d, (hipStream_t)stream);
 }
 int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
                      int nkv_pad, int d, float scale, void* stream) {

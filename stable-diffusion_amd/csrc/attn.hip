@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
         if (dd < D) {
           f16x4 v = {(f16)(o[dt][r4 * 4 + 0] * inv), (f16)(o[dt][r4 * 4 + 1] * inv), (f16)(o[dt][r4 * 4 + 2] * inv),
                      (f16)(o[dt][r4 * 4 + 3] * inv)};
-          *(f16x4*)(orow + dd) = v;
+          SDMI_ST(f16x4, orow + dd, v);
         }
       }
   }

@@ -63,6 +63,15 @@ static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * 
 // ----------------------------------------------------------------------------------------------
 enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 
+// Output stores of the big producers (GEMM epilogues, split-K reduce, GroupNorm-apply, LayerNorm, attention): nothing inside the
+// producing kernel reads them back, the next kernel does.  -DSDMI_NT_STORES marks them non-temporal (experiment: does streaming
+// them out shorten the write-back at the kernel boundary?  SDMI_CXXFLAGS=-DSDMI_NT_STORES SDMI_LIB_OUT=libsdmi_nt.so build.py).
+#ifdef SDMI_NT_STORES
+#define SDMI_ST(T, ptr, val) __builtin_nontemporal_store((T)(val), (T*)(ptr))
+#else
+#define SDMI_ST(T, ptr, val) (*(T*)(ptr) = (T)(val))
+#endif
+
 struct IGemmParams {
   const f16* a0 = nullptr; const f16* a1 = nullptr; const f16* a2 = nullptr;   // A sources, channel concat [a0 | a1 | a2]
   int c0 = 0, c1 = 0, c2 = 0;                          // channels taken from each source (Cin = c0 + c1 + c2)
@@ -91,6 +100,20 @@ struct IGemmParams {
   // launch_igemm issues the layernorm kernel after the GEMM (and its split-K reduce).  A reduce kernel with the
   // LayerNorm folded in (one wave per row) was measured and was no faster than the two launches.
   const float* ln_gamma = nullptr; const float* ln_beta = nullptr; f16* ln_out = nullptr; float ln_eps = 1e-5f;
+  // ---- LayerNorm folded into the CONSUMING GEMM (attention.py:211-215: x + attn1(norm1(x)), ... -- no LayerNorm launch) --------
+  //   sum_k LN(x)_k W_nk = rstd_m * ( sum_k (gamma_k x_k) W_nk  -  mean_m * cs_n ) + d_n,   cs_n = sum_k gamma_k W_nk,
+  //                                                                                          d_n  = sum_k beta_k W_nk (+ bias_n)
+  // Producer side (plain mode, the GEMM whose output rows x a LayerNorm reads): beside the fp32 stream it stores the operand
+  // fp16(gamma_n * x) through out_f16 (f16_scale = gamma: one rounding, as the stand-alone kernel rounds LN(x) once) and the
+  // {sum, sum of squares} of every row over each 32-column block of its tile: lnp_out[(n / 32) * M + m] (float2).  Needs the
+  // 16-byte epilogue (full tiles inside one sample, N % BN == 0: the launcher picks such a tile) and no split-K.
+  const float* f16_scale = nullptr;                    // [N] fp32, multiplies the out_f16 copy only
+  float* lnp_out = nullptr;                            // [N / 32][M][2] fp32 row-statistics partials
+  // Consumer side (any mode): a0 = that fp16(gamma * x) operand [M][K]; lnf_part = its row partials ([lnf_npart = K / 32][M][2]),
+  // folded per row in the prologue (fp64) into {mean, rstd}; the epilogue turns every accumulator into
+  // rstd_m * (acc - mean_m * lnf_cs[n]) + lnf_d[n] before its mode-specific part (bias must be NULL: it is inside lnf_d).
+  const float* lnf_part = nullptr; int lnf_npart = 0; float lnf_eps = 1e-5f;
+  const float* lnf_cs = nullptr; const float* lnf_d = nullptr;
   // EPI_HEADS: N = nseg * C, column n -> segment n / C, head (n % C) / dh, dd = n % dh
   //   seg_kind 0: row layout   dst[((b*heads + head) * ntok + tok) * dh + dd]
   //   seg_kind 1: transposed   dst[((b*heads + head) * dh + dd) * ntok_pad + tok]
@@ -113,6 +136,7 @@ struct IGemmParams {
 #endif
   int splitk_fused = 0;                                // set by the launcher
   int epi_vec = 0;                                     // set by the launcher: 16-byte epilogue (pointer / pitch alignment checked there)
+  int epi_pre = 0;                                     // set by the launcher: residual quads of that epilogue fetched in the kernel prologue (small tiles)
   int tile_n_fastest = 0;                              // set by the launcher: tile numbering inside an XCD's range
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
   // optional (plain mode): GroupNorm(32) statistics of the finished output for up to two consuming GroupNorms -- the
@@ -255,6 +279,10 @@ int launch_prefetch_lines(const void* ptr, int64_t bytes, hipStream_t s);
 // weight packing (device pointers, fp32 reference layouts -> packed)
 int launch_pack_conv_weight(const float* w_oihw, f16* dst, int O, int I, int KH, int KW, hipStream_t s);  // -> [O][KH][KW][I]
 int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0, int dst_ld, hipStream_t s);
+// column terms of a GEMM that folds LayerNorm(gamma, beta) of its input rows (IGemmParams::lnf_cs / lnf_d), from the PACKED fp16
+// weights: cs[n] = sum_k gamma[k] w[n][k], d[n] = sum_k beta[k] w[n][k] (+ bias[n])
+int launch_ln_fold_prep(const f16* w, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias, float* cs,
+                        float* d, hipStream_t s);
 // split-fp16 weights for the 3-pass 1x1 convs: dst [N][3K] = [hi | hi | lo], lo = fp16(w - float(hi))
 int launch_pack_split3(const float* w, f16* dst, int N, int K, hipStream_t s);
 int launch_pack_geglu(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K, hipStream_t s);

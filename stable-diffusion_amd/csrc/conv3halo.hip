@@ -278,6 +278,14 @@ __device__ __forceinline__ void static_for(F&& f) {
 // Schedule of the halo pieces of conv3halo_gn_kernel inside the nine taps of a channel chunk (all compile-time):
 // piece q is loaded at tap LT(q) (taps 0 .. 6; with 8 or 9 pieces two at taps 0 and 1) and converted LAG taps later.  Order of
 // the vector-memory issues inside a tap: [register loads of the tap's pieces (gamma / beta in front of piece 0)] [PB weight pieces].
+//
+// Counted waits, per DESTINATION CLASS.  The kernel has two kinds of loads in flight: LDS-DMA (weights) and loads into registers
+// (the fp32 halo).  Round 3 measured (profiles/gn_fold_r03.txt) that ONE in-order queue across both is not what the hardware
+// retires: with "everything younger than X may be outstanding" as the vmcnt literal, weight tiles were read before they had
+// landed whenever the activations were L2-hot and the weights HBM-cold (inside a UNet call; never in a stand-alone repetition),
+// and draining the queue at every wait (SDMI_GN_SAFE=1) cured it.  The literals below therefore count only the younger
+// operations of the SAME class: total outstanding <= n implies outstanding-of-that-class <= n, and within a class retirement is
+// in order (the LDS-DMA-only kernels rely on exactly that).  Also safe under a single in-order queue (the literal only shrinks).
 template <int AHP, int PB, int NS, int LAG>
 struct HaloGnSched {
   static constexpr int LT(int q) { return AHP <= 7 ? q : (q < 4 ? q / 2 : q - 2); }
@@ -287,22 +295,18 @@ struct HaloGnSched {
     return n + (t == 0 ? 4 : 0);
   }
   static constexpr int vmem_at(int t) { return loads_at(((t % 9) + 9) % 9) + PB; }
-  // operations that may be outstanding when piece q is converted at tap LT(q) + LAG: everything issued after its two loads --
-  // the later pieces of its own tap, that tap's weights, the whole taps in between, and the conversion tap's loads (issued first)
+  // register loads that may be outstanding when piece q is converted at tap LT(q) + LAG: the later pieces of its own tap, the
+  // loads of the taps in between and of the conversion tap (issued in front of the conversions)
   static constexpr int after_piece(int q) {
     int n = 0;
     for (int q2 = q + 1; q2 < AHP; ++q2) n += (LT(q2) == LT(q)) ? 2 : 0;
-    n += PB;
-    for (int t = LT(q) + 1; t < LT(q) + LAG; ++t) n += vmem_at(t);
-    return n + loads_at(LT(q) + LAG);
-  }
-  // what may still be in flight when weight tile kt + 1 is needed at the end of tap t: everything issued in the last NS - 2
-  // taps (that tile's pieces were the last issues of tap t - (NS - 2))
-  static constexpr int in_flight_ok(int t) {
-    int n = 0;
-    for (int d = 0; d < NS - 2; ++d) n += vmem_at(t - d + 18);
+    for (int t = LT(q) + 1; t <= LT(q) + LAG; ++t) n += loads_at(t);
     return n;
   }
+  // LDS-DMA pieces that may be outstanding when weight tile kt + 1 is needed at the end of tap t: those of the last NS - 2 taps
+  // (that tile's pieces were the DMA issues of tap t - (NS - 2)); the last chunk's place-holder issues are DMA pieces too and
+  // only make the real count larger than the literal
+  static constexpr int in_flight_ok(int) { return PB * (NS - 2); }
 };
 
 // ---- halo-staged 3x3 convolution with GroupNorm(32) + SiLU folded into the staging --------------------------------------

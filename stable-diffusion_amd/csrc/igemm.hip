@@ -79,6 +79,14 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   const int tid = threadIdx.x;
   SDMI_STAMP(dbg_t0);
+  // LayerNorm of the A rows folded into this GEMM: the row-statistics partials are requested first of all (see lnf_request)
+  float2 lnf_pv[LNF_MAXP];
+  float lnf_mean = 0.f, lnf_rstd = 1.f;
+  const bool lnf_mine = p.lnf_part != nullptr && tid < BM;
+  if (lnf_mine) lnf_request(p, min(m0 + tid, p.M - 1), lnf_pv);
+  // ... and so are the residual quads of the epilogue (small tiles only, see epi_prefetch_residual)
+  f32x4 pre_res[4];
+  const bool pre_ok = p.epi_pre && epi_prefetch_residual<BM, BN, WARPS_M, WARPS_N>(p, m0, n0, pre_res);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int cpos = tid & 7;                      // chunk position inside the LDS row
@@ -262,6 +270,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   };
 
   SDMI_STAMP(dbg_t1);
+  if constexpr (!DMA) { if (lnf_mine) lnf_finish(p, lnf_pv, &lnf_mean, &lnf_rstd); }
   if constexpr (DMA) {
     // Software pipeline (one raw s_barrier per k-tile, NS - 1 LDS-DMA tiles in flight across it):
     //   * fragments are double buffered in registers: the ds_reads of k-step s + 1 are issued before the MFMAs of
@@ -282,6 +291,9 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     constexpr int MPU = G * TM * TN;               // MFMAs per unit
 #pragma unroll
     for (int s = 0; s < NS - 1; ++s) issue_loads(s);
+    // LayerNorm folded into this GEMM: fold the row statistics requested at the top.  The explicit drain: register loads and
+    // LDS-DMA do not retire through one in-order queue (profiles/gn_fold_r03.txt), so a counted wait across both is not sound
+    if (p.lnf_part) { wait_vmcnt<0>(); if (lnf_mine) lnf_finish(p, lnf_pv, &lnf_mean, &lnf_rstd); }
     wait_vmcnt<LPT*(NS - 2)>();
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
     f16x8 fa[2][G][TM], fb[2][G][TN];
@@ -339,7 +351,8 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   // ---- epilogue ------------------------------------------------------------------------------------
   SDMI_STAMP(dbg_t2);
-  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
+  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem, lnf_mean, lnf_rstd,
+                                                             pre_ok ? pre_res : nullptr);
 #ifdef SDMI_IGEMM_TIMING
   if (p.dbg_times && tid == 0) {        // (where a workgroup's time goes; blocks that return early in the epilogue are not stamped)
     long long* d = p.dbg_times + 6 * (size_t)blockIdx.x;      // d[3] = after the output stores (written inside the epilogue)
@@ -394,8 +407,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
     v += biasv;
     if (p.rowvec) v += rvv;
     if (p.residual) v += resv;
-    if (p.out_f32) *(f32x4*)(p.out_f32 + (size_t)m * p.ldo + n) = v;
-    if (p.out_f16) *(f16x4*)(p.out_f16 + (size_t)m * p.ldo + n) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    if (p.out_f32) SDMI_ST(f32x4, p.out_f32 + (size_t)m * p.ldo + n, v);
+    if (p.out_f16) SDMI_ST(f16x4, p.out_f16 + (size_t)m * p.ldo + n, (f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}));
     if (p.out_lo) {
       f16x4 lo;
 #pragma unroll
@@ -475,6 +488,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
+  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 1) && nsplit == 1;      // (read per launch: A/B knob, bit-identical results)
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
@@ -685,6 +699,7 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
     // samples per candidate
     if (!p.split16 && ((c.ns == 2 && t != 11 && !tile_is_halo(t)) || t == 12 || t == 13)) continue;
     if (p.mode == EPI_GEGLU && !tile_tn_even(t)) continue;
+    if (p.lnp_out && (p.M % c.bm || p.N % c.bn || (p.Hout * p.Wout) % c.bm)) continue;   // row statistics: full tiles inside one sample
     const long blocks = (long)cdiv(p.M, c.bm) * cdiv(p.N, c.bn);
     if ((long)c.bm > 2L * p.M && c.bm > 64) continue;                  // tile mostly padding
     if ((long)c.bn > 2L * p.N && c.bn > 64) continue;
@@ -806,6 +821,14 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && p.ldo == p.N && p.N % 4 == 0 && p.N <= 2560 && p.ln_gamma && p.ln_beta,
                "LayerNorm post-op needs plain mode, an fp32 output with ldo == N <= 2560, gamma and beta");
   if (p.out_lo) SDMI_CHECK(p.mode == EPI_PLAIN && p.ldo % 4 == 0, "out_lo needs plain mode");
+  if (p.lnp_out || p.f16_scale)        // producer of a LayerNorm that its consumer folds (IGemmParams::lnp_out)
+    SDMI_CHECK(p.mode == EPI_PLAIN && p.out_f32 && p.out_f16 && !p.out_lo && !p.ln_out && p.N % 64 == 0 && p.M % 64 == 0 &&
+                   (p.Hout * p.Wout) % 64 == 0 && p.splitk == 1 && epi_vec_ok(p),
+               "LayerNorm row statistics: plain mode, fp32 + fp16 outputs, no split-K, M / N / rows per sample multiples of 64, 16-byte aligned rows");
+  if (p.lnf_part)                      // consumer that folds the LayerNorm of its A rows (IGemmParams::lnf_*)
+    SDMI_CHECK(p.ksize == 1 && p.c1 == 0 && p.c2 == 0 && !p.split16 && p.lnf_npart * 32 == p.K && p.lnf_cs && p.lnf_d && !p.bias &&
+                   p.splitk == 1 && p.lnf_npart <= 20,
+               "LayerNorm-folding GEMM: dense, one source, K = 32 * lnf_npart <= 640, column sums + offsets, no bias, no split-K");
   if (p.gn_n) {
     SDMI_CHECK(p.mode == EPI_PLAIN && p.gn_n <= 2 && (p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need plain mode and Hout*Wout % 32 == 0");
     SDMI_CHECK(p.N % 4 == 0, "GroupNorm statistics: N % 4 == 0");
@@ -930,6 +953,12 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
     if (p.mode == EPI_GEGLU) tile = 0;
     else if (p.mode == EPI_HEADS) tile = 2;
     else tile = gflop >= 25.0 ? 3 : 5;
+  }
+  if (p.lnp_out) {
+    // the row statistics ride on the 16-byte epilogue: every tile full and inside one sample -- a table / heuristic tile that
+    // does not divide this shape gives way to the 64 x 64 one (3 stages), which does (checked above)
+    const int hw = p.Hout * p.Wout;
+    if (p.M % kTiles[tile].bm || p.N % kTiles[tile].bn || hw % kTiles[tile].bm || (p.split16 && !split16_tile_supported(tile))) tile = 5;
   }
   if (splitk <= 0) {  // auto: enough blocks to keep bytes in flight on all 256 CUs, >= 8 k-tiles per split
     splitk = 1;

@@ -112,6 +112,72 @@ __device__ __forceinline__ void slab_get(const float* wl, f32x16 (&a)[TN], int l
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
+// Row statistics of a GEMM that folds the LayerNorm of its input rows (IGemmParams::lnf_*): the producer left {sum, sum of
+// squares} per 32-column block.  lnf_request: thread i < BM asks for the partials of row m at the very top of the kernel (plain
+// loads, up to LNF_MAXP blocks = 640 channels); lnf_finish folds them (block order, fp32: deterministic) once the operand
+// prologue has been issued -- the first version fetched and folded (fp64) between the DMA issue and the first barrier, two
+// dependent round trips + a double-precision rsqrt on every workgroup's critical path: +7 us on a 640-workgroup GEMM.
+constexpr int LNF_MAXP = 20;
+__device__ __forceinline__ void lnf_request(const IGemmParams& p, int m, float2 (&pv)[LNF_MAXP]) {
+  const float2* src = (const float2*)p.lnf_part + m;
+#pragma unroll
+  for (int j = 0; j < LNF_MAXP; ++j) pv[j] = src[(size_t)min(j, p.lnf_npart - 1) * p.M];
+}
+__device__ __forceinline__ void lnf_finish(const IGemmParams& p, const float2 (&pv)[LNF_MAXP], float* mean, float* rstd) {
+  float s = 0.f, q = 0.f;
+#pragma unroll
+  for (int j = 0; j < LNF_MAXP; ++j)
+    if (j < p.lnf_npart) { s += pv[j].x; q += pv[j].y; }
+  const float inv_c = 1.0f / (32.0f * (float)p.lnf_npart);
+  const float mu = s * inv_c;
+  const float var = fmaxf(q * inv_c - mu * mu, 0.f);
+  *mean = mu;
+  *rstd = 1.0f / sqrtf(var + p.lnf_eps);
+}
+// sum over aligned groups of 8 lanes, in every lane of the group (three DPP adds: quad_perm xor 1, xor 2, row_half_mirror)
+__device__ __forceinline__ float sum8_dpp(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+  return v;
+}
+
+// Residual quads of the 16-byte epilogue requested in the kernel PROLOGUE: the short-K GEMMs on the residual stream (to_out, FF2,
+// proj_out: 5-20 k-tiles) otherwise end with a dependent load -> add -> store chain per workgroup, with every co-resident
+// workgroup in it at the same time.  Only for tiles whose lane needs <= 4 quads (64 x 64, 4 waves: 16 VGPRs through the k-loop),
+// and only when the epilogue will take its 16-byte path for this tile (same predicate as in igemm_epilogue).  In-place
+// residuals (out == residual) are fine: a workgroup reads its own tile before it writes it.
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+struct EpiPre {
+  static constexpr int WTN = BN / WARPS_N, TM = BM / WARPS_M / 32;
+  static constexpr int NP = (WTN == 32 || WTN == 64) ? SLAB_NPASS<(WTN == 32 || WTN == 64) ? WTN : 32> : 0;
+  static constexpr int NQ = TM * NP;
+  static constexpr bool OK = NQ >= 1 && NQ <= 4;
+};
+template <int BM, int BN, int WARPS_M, int WARPS_N>
+__device__ __forceinline__ bool epi_prefetch_residual(const IGemmParams& p, int m0, int n0, f32x4 (&r)[4]) {
+  using E = EpiPre<BM, BN, WARPS_M, WARPS_N>;
+  if constexpr (!E::OK) { return false; }
+  else {
+    constexpr int WTM = BM / WARPS_M, WTN = E::WTN;
+    const int HWout = p.Hout * p.Wout;
+    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    const bool one_batch = ((m0 + BM - 1) / HWout == m0 / HWout);
+    const bool want = p.mode == EPI_PLAIN && p.residual && p.epi_vec && full && one_batch && p.splitk <= 1;
+    if (!want) return false;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
+    const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
+    const int rl = lane / SLAB_LPR<WTN>, c4 = (lane % SLAB_LPR<WTN>) * 4;
+#pragma unroll
+    for (int i = 0; i < E::TM; ++i)
+#pragma unroll
+      for (int q = 0; q < E::NP; ++q)
+        r[i * E::NP + q] = *(const f32x4*)(p.residual + (size_t)(mw + i * 32 + q * SLAB_RPI<WTN> + rl) * p.ldr + nw + c4);
+    return true;
+  }
+}
+
 // The epilogue shared by the GEMM kernels (generic implicit GEMM and the halo-staged 3x3 convolution): accumulators of the
 // wave's TM x TN MFMA tiles -> bias / time-embedding row vector / residual / fp32 + fp16 (+ split-fp16 low half) stores,
 // GEGLU, per-head q / k / v^T scatter, split-K slabs, GroupNorm statistics.  `smem` = the block's LDS (free at this point:
@@ -119,7 +185,8 @@ __device__ __forceinline__ void slab_get(const float* wl, f32x16 (&a)[TN], int l
 template <int BM, int BN, int WARPS_M, int WARPS_N, int LDS_BYTES>
 __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 (&acc)[BM / WARPS_M / 32][BN / WARPS_N / 32],
                                                const int m0, const int n0, const int split, const int tile_m,
-                                               const int tile_n, unsigned char* smem) {
+                                               const int tile_n, unsigned char* smem, const float lnf_mean = 0.f,
+                                               const float lnf_rstd = 1.f, const f32x4* pre_res = nullptr) {
 #ifdef SDMI_IGEMM_TIMING
   IGemmParams p = p_arg;                                  // timing build: epilogue ablations (wrong results, time only)
   if (p.dbg_abl & 1) p.residual = nullptr;
@@ -208,6 +275,27 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
     }
     __syncthreads();                       // smem[0] is reused below
   }
+  if (p.lnf_part) {
+    // ---- LayerNorm of the A rows folded into this GEMM (IGemmParams::lnf_*): thread i < BM brought {mean, rstd} of row m0 + i
+    // (lnf_row_stats, kernel prologue); through an LDS table every lane picks up the rows of its accumulator registers ----
+    __syncthreads();                                       // every wave's LDS-DMA has landed, nobody reads the tiles any more
+    float2* const tab = (float2*)smem;
+    if (tid < BM) tab[tid] = float2{lnf_mean, lnf_rstd};
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = min(nw + j * 32 + l31, p.N - 1);
+      const float cs = p.lnf_cs[n], dn = p.lnf_d[n];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float2 mr = tab[wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg];
+          acc[i][j][r] = fmaf(mr.y, acc[i][j][r] - mr.x * cs, dn);
+        }
+    }
+    __syncthreads();                                       // the table is read: the LDS is free for the slabs / statistics below
+  }
   const bool unfused_split = p.splitk > 1 && !p.splitk_fused;
   if (p.mode == EPI_PLAIN) {
     const bool atomic = unfused_split;     // unfused split-K: raw partial sums go to this split's slab
@@ -228,12 +316,17 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
       f32x4 colv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) colv = *(const f32x4*)(p.bias + nw + c4);
       if (p.rowvec) colv += *(const f32x4*)(p.rowvec + (size_t)b_first * p.ld_rowvec + nw + c4);
+      f32x4 g4 = {1.f, 1.f, 1.f, 1.f};                     // scale of the fp16 copy (a LayerNorm's gamma when its consumer folds it)
+      if (p.f16_scale) g4 = *(const f32x4*)(p.f16_scale + nw + c4);
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         slab_put<TN, LSTR>(wl, acc[i], l31, lg);
         constexpr int NP = SLAB_NPASS<WTN>, RPI = SLAB_RPI<WTN>;
         f32x4 resv[NP];
-        if (p.residual) {
+        if (pre_res) {                                     // fetched in the kernel prologue (epi_prefetch_residual)
+#pragma unroll
+          for (int q = 0; q < NP; ++q) resv[q] = pre_res[i * NP + q];
+        } else if (p.residual) {
 #pragma unroll
           for (int q = 0; q < NP; ++q)
             resv[q] = *(const f32x4*)(p.residual + (size_t)(mw + i * 32 + q * RPI + rl) * p.ldr + nw + c4);
@@ -247,12 +340,22 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
           float* const lp = wl + row * LSTR + c4;
           const f32x4 v = *(const f32x4*)lp + colv + resv[q];
           const size_t ro = (size_t)(mw + i * 32 + row) * p.ldo + nw + c4;
-          if (p.out_f32) *(f32x4*)(p.out_f32 + ro) = v;
-          const f16x4 h = {(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
-          if (p.out_f16) *(f16x4*)(p.out_f16 + ro) = h;
+          if (p.out_f32) SDMI_ST(f32x4, p.out_f32 + ro, v);
+          const f32x4 vs = v * g4;                         // (g4 = 1 without a scale: exact)
+          const f16x4 h = {(f16)vs[0], (f16)vs[1], (f16)vs[2], (f16)vs[3]};
+          if (p.out_f16) SDMI_ST(f16x4, p.out_f16 + ro, h);
           if (p.out_lo)
             *(f16x4*)(p.out_lo + ro) = f16x4{(f16)(v[0] - (float)h[0]), (f16)(v[1] - (float)h[1]), (f16)(v[2] - (float)h[2]),
                                             (f16)(v[3] - (float)h[3])};
+          if (p.lnp_out) {
+            // row statistics of the finished values for the LayerNorm that reads them: {sum, sum of squares} over this row's
+            // 32-column block = the 8 lanes that hold it (fixed DPP add tree: deterministic), one float2 per (block, row)
+            float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+            float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            s1 = sum8_dpp(s1); s2 = sum8_dpp(s2);
+            if ((lane & 7) == 0)
+              *(float2*)(p.lnp_out + 2 * ((size_t)((nw + c4) >> 5) * p.M + (size_t)(mw + i * 32 + row))) = float2{s1, s2};
+          }
           if (p.gn_n > 0) *(f32x4*)lp = v;                 // final values back for the statistics below
         }
         if (p.gn_n > 0) slab_get<TN, LSTR>(wl, acc[i], l31, lg);
@@ -427,7 +530,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
               const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lg;
               const float val = acc[i][2 * j2][r] + bv;
               const float gate = acc[i][2 * j2 + 1][r] + bg;
-              p.out_f16[(size_t)m * p.ldo + oc] = (f16)(val * gelu_erf(gate));
+              SDMI_ST(f16, p.out_f16 + (size_t)m * p.ldo + oc, (f16)(val * gelu_erf(gate)));
             }
         } else {
 #pragma unroll
@@ -501,7 +604,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
               const int b = m / p.ntok;
               const int tok = m - b * p.ntok;
               const f32x4 a = *(const f32x4*)(wl + row * LSTR + c4);
-              *(f16x4*)(dst + (((size_t)b * p.heads + head) * p.ntok + tok) * p.dh + dd) = f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]};
+              SDMI_ST(f16x4, dst + (((size_t)b * p.heads + head) * p.ntok + tok) * p.dh + dd, (f16x4{(f16)a[0], (f16)a[1], (f16)a[2], (f16)a[3]}));
             }
           }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // slab reads done before the next slab_put overwrites them

@@ -158,9 +158,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const 
       y[j] = gn_apply_elem(v[u][j], second ? m1 : m0, second ? r1 : r0, ga[u][j], be[u][j], p.silu);
     }
     const size_t o = pix[u] * C + c;
-    if (p.out_f16) *(f16x4*)(p.out_f16 + o) = f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]};
-    if (p.out_lo) *(f16x4*)(p.out_lo + o) = lo_half(y);
-    if (p.out_f32) *(f32x4*)(p.out_f32 + o) = y;
+    if (p.out_f16) SDMI_ST(f16x4, p.out_f16 + o, (f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]}));
+    if (p.out_lo) SDMI_ST(f16x4, p.out_lo + o, lo_half(y));
+    if (p.out_f32) SDMI_ST(f32x4, p.out_f32 + o, y);
     if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[u][0], (f16)v[u][1], (f16)v[u][2], (f16)v[u][3]};
     if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v[u]);
   }
@@ -206,7 +206,7 @@ __global__ void __launch_bounds__(256) layernorm_kernel(const float* x, const fl
       f32x4 y32;
 #pragma unroll
       for (int j = 0; j < 4; ++j) y32[j] = (v[i][j] - mean) * rstd * ga[j] + be[j];
-      if (out) *(f16x4*)(out + (size_t)row * C + c) = f16x4{(f16)y32[0], (f16)y32[1], (f16)y32[2], (f16)y32[3]};
+      if (out) SDMI_ST(f16x4, out + (size_t)row * C + c, (f16x4{(f16)y32[0], (f16)y32[1], (f16)y32[2], (f16)y32[3]}));
       if (out32) *(f32x4*)(out32 + (size_t)row * C + c) = y32;
     }
   }

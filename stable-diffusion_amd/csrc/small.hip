@@ -572,6 +572,29 @@ int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0,
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
+
+// LayerNorm folded into the consuming GEMM (attention.py:211-215; IGemmParams::lnf_*): the two column vectors, computed from the
+// fp16 weights the MFMAs will multiply (so that mean * cs cancels the mean's share of the accumulator exactly as far as the
+// weights go).  One wave per weight row, lanes stride over K, fixed butterfly: deterministic.
+__global__ void __launch_bounds__(256) ln_fold_prep_kernel(const f16* w, int N, int K, int ldw, const float* gamma, const float* beta,
+                                                           const float* bias, float* cs, float* d) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const f16* row = w + (size_t)n * ldw;
+  float a = 0.f, b = 0.f;
+  for (int k = lane; k < K; k += 64) { const float wv = (float)row[k]; a = fmaf(gamma[k], wv, a); b = fmaf(beta[k], wv, b); }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if (lane == 0) { cs[n] = a; d[n] = b + (bias ? bias[n] : 0.f); }
+}
+int launch_ln_fold_prep(const f16* w, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias, float* cs,
+                        float* d, hipStream_t s) {
+  SDMI_CHECK(w && gamma && beta && cs && d && N > 0 && K > 0 && ldw >= K, "ln_fold_prep: bad arguments");
+  hipLaunchKernelGGL(ln_fold_prep_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s, w, N, K, ldw, gamma, beta, bias, cs, d);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
 int launch_pack_split3(const float* w, f16* dst, int N, int K, hipStream_t s) {
   const int64_t total = (int64_t)N * K;
   hipLaunchKernelGGL(pack_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, N, K);

@@ -47,6 +47,8 @@ int UNet::build(const sdmi_unet_cfg& c) {
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_FUSE_GN_STATS")) fuse_gn_stats_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_SIDE_STREAM")) side_stream_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_LN_FOLD")) ln_fold_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_LN_FOLD_MIN_ROWS")) ln_fold_min_rows_ = atoi(e);
   const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
 
   auto add_res = [&](const std::string& p, int cin, int cout) {
@@ -344,6 +346,29 @@ int UNet::finalize() {
     SDMI_HIP_OK(hipMemset(zero_, 0, 4096));
   }
   if (reserve_ctx_cache(8, 77)) return -1;       // default K/V capacity (a no-op once reserved)
+  // column terms of the GEMMs that fold a LayerNorm of their input rows (derived from the packed weights: not part of the blob)
+  {
+    SDMI_HIP_OK(hipDeviceSynchronize());          // (the packing kernels ran on the caller's streams; finalize is off the hot path)
+    auto each = [&](Layer& L) -> int {
+      if (L.kind != L_ATTN) return 0;
+      const int C = L.cin;
+      for (auto& T : L.tb) {
+        const int n_[3] = {3 * C, C, 8 * C};
+        const f16* w_[3] = {T.wqkv, T.wq2, T.wgg};
+        const float* b_[3] = {nullptr, nullptr, T.bgg};
+        for (int i = 0; i < 3; ++i) {
+          if (dev_alloc((void**)&T.lnf[2 * i], (size_t)n_[i] * sizeof(float)) || dev_alloc((void**)&T.lnf[2 * i + 1], (size_t)n_[i] * sizeof(float)))
+            return -1;
+          if (launch_ln_fold_prep(w_[i], n_[i], C, C, T.ln[2 * i], T.ln[2 * i + 1], b_[i], T.lnf[2 * i], T.lnf[2 * i + 1], nullptr)) return -1;
+        }
+      }
+      return 0;
+    };
+    for (auto& blk : input_blocks_) for (auto& L : blk) if (each(L)) return -1;
+    for (auto& L : middle_) if (each(L)) return -1;
+    for (auto& blk : output_blocks_) for (auto& L : blk) if (each(L)) return -1;
+    SDMI_HIP_OK(hipDeviceSynchronize());
+  }
   finalized_ = true;
   return 0;
 }
@@ -426,6 +451,7 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
 // ------------------------------------------------------------------------------------------------------
 struct Fwd : FwdBase {
   UNet* u; int Lctx;
+  bool ln_fold_on = false;      // this call folds LayerNorms into their consuming GEMMs (UNet::ln_fold_; read per call: A/B knobs)
   float* emb_all = nullptr;     // [B][emb_total] (emb_ld = emb_total), or one row of the timestep table shared by every sample (emb_ld = 0)
   int emb_ld = 0;
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
@@ -534,10 +560,19 @@ struct Fwd : FwdBase {
     f16* vt = S<f16>((size_t)B * C * Np);
     f16* ao = S<f16>((size_t)M * C);
     f16* gg = S<f16>((size_t)M * 4 * C);
-    // Every LayerNorm of the block reads the token stream `t` right after the GEMM that produced it, so it rides on
-    // that GEMM as a post-op (launch_igemm issues it after the GEMM / its split-K reduce): ln = LN(t).
+    // Every LayerNorm of the block reads the token stream `t` right after the GEMM that produced it.  Two forms:
+    //  * folded into the GEMM that READS it (IGemmParams::lnp_out / lnf_*): the producer stores ln = fp16(gamma * t) and the row
+    //    statistics, the consumer corrects its accumulators -- no launch; taken where the producer is not split (many rows);
+    //  * a post-op launch behind the producer (launch_igemm issues it after the GEMM / its split-K reduce): ln = LN(t).
+    const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 640 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
+    float* lnp = fold_ln ? S<float>((size_t)(C / 32) * M * 2) : nullptr;
     auto with_ln = [&](IGemmParams& p, const float* gamma, const float* beta) {
-      p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = ln; p.ln_eps = 1e-5f;
+      if (fold_ln) { p.out_f16 = ln; p.f16_scale = gamma; p.lnp_out = lnp; p.splitk = 1; }
+      else { p.ln_gamma = gamma; p.ln_beta = beta; p.ln_out = ln; p.ln_eps = 1e-5f; }
+    };
+    auto fold_in = [&](IGemmParams& p, const float* cs, const float* dn) {      // the GEMM that reads `ln`
+      if (!fold_ln) return;
+      p.lnf_part = lnp; p.lnf_npart = C / 32; p.lnf_eps = 1e-5f; p.lnf_cs = cs; p.lnf_d = dn; p.bias = nullptr;
     };
     {
       IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N);
@@ -554,6 +589,7 @@ struct Fwd : FwdBase {
         p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_dst[1] = k; p.seg_dst[2] = vt;
         p.seg_kind[0] = 0; p.seg_kind[1] = 0; p.seg_kind[2] = 1;
         p.heads = L.heads; p.dh = L.dh; p.ntok = N; p.ntok_pad = Np; p.segC = C; p.splitk = 1;
+        fold_in(p, T.lnf[0], T.lnf[1]);
         if (!dry && !rc && Np != N) {
           hipError_t e = hipMemsetAsync(vt, 0, (size_t)B * C * Np * sizeof(f16), s);
           if (e != hipSuccess) ok(fail(std::string("hipMemsetAsync: ") + hipGetErrorString(e)));
@@ -572,6 +608,7 @@ struct Fwd : FwdBase {
         IGemmParams p = dense(ln, M, C, T.wq2, C, N);
         p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_kind[0] = 0;
         p.heads = L.heads; p.dh = L.dh; p.ntok = N; p.ntok_pad = Np; p.segC = C; p.splitk = 1;
+        fold_in(p, T.lnf[2], T.lnf[3]);
         gemm(p);
       }
       if (ctx16) context_kv(L, d);
@@ -586,6 +623,7 @@ struct Fwd : FwdBase {
       {
         IGemmParams p = dense(ln, M, C, T.wgg, 8 * C, N);
         p.mode = EPI_GEGLU; p.bias = T.bgg; p.out_f16 = gg; p.ldo = 4 * C; p.splitk = 1;
+        fold_in(p, T.lnf[4], T.lnf[5]);
         gemm(p);
       }
       {
@@ -756,6 +794,11 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
 
   Fwd f;
   f.u = this; f.s = stream; f.dry = dry; f.B = B; f.Lctx = Lctx; f.zero = zero_; f.precise_1x1 = precise_1x1_;
+  {
+    // (both knobs are read per call -- the tests flip them between two forwards; the row statistics ride on the 16-byte epilogue)
+    const char* e_fold = getenv("SDMI_LN_FOLD"); const char* e_vec = getenv("SDMI_EPI_VEC");
+    f.ln_fold_on = (e_fold ? atoi(e_fold) != 0 : ln_fold_) && !(e_vec && atoi(e_vec) == 0);
+  }
   if (side_stream_ && !dry && !prof_enabled()) {      // (the per-launch profiler times launches on one stream)
     if (!side_) {
       SDMI_HIP_OK(hipStreamCreateWithFlags(&side_, hipStreamNonBlocking));

@@ -241,6 +241,9 @@ struct TBlock {   // BasicTransformerBlock (ldm/modules/attention.py:196-215)
   f16* wff2 = nullptr; float* bff2 = nullptr;
   float* ln[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
   f16* ck = nullptr; f16* cvt = nullptr;        // cached cross-attention K [B*h][L][d] and V^T [B*h][d][Lpad]
+  // LayerNorm folded into the consuming GEMM (IGemmParams::lnf_cs / lnf_d; computed by finalize() from the packed weights):
+  // {cs, d} of attn1 q|k|v with norm1, attn2 to_q with norm2, the GEGLU projection with norm3 (packed column order, bias inside d)
+  float* lnf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
 };
 
 struct Layer {
@@ -308,6 +311,10 @@ class UNet {
   bool side_stream_ = false;    // SDMI_SIDE_STREAM=1: ResBlock skip convolutions on a side stream (measured 3 % slower)
   hipStream_t side_ = nullptr; hipEvent_t side_ev_[32] = {};
   bool fuse_gn_stats_ = true;   // SDMI_FUSE_GN_STATS=0: every GroupNorm runs its own statistics kernel (A/B, debugging)
+  // The LayerNorms of a BasicTransformerBlock (attention.py:211-215) folded into the GEMMs that read them, where the producing
+  // GEMM is not split (>= ln_fold_min_rows_ token rows): no LayerNorm launch, one fp32 read of the token stream less per site.
+  // SDMI_LN_FOLD=0 restores the launches (A/B); SDMI_LN_FOLD_MIN_ROWS moves the threshold.
+  bool ln_fold_ = true; int ln_fold_min_rows_ = 2048;
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
   std::vector<Layer> middle_;

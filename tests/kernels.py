@@ -43,8 +43,9 @@ def cast_f16(x, want_lo=False):
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
           residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None, fused_splitk=True,
-          asym_pad=0, gn=None, split16=False):
-    """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K]."""
+          asym_pad=0, gn=None, split16=False, f16_scale=None, lnp_out=None, lnf=None):
+    """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K].
+    LayerNorm fold: producer f16_scale (gamma [N]) + lnp_out ([N/32, M, 2] fp32); consumer lnf = (partials, eps, cs, d)."""
     d = _lib.IGemmDesc()
     d.a0 = a0.data_ptr(); d.c0 = a0.shape[1]; d.lda0 = a0.stride(0)
     if a1 is not None:
@@ -68,6 +69,11 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
     d.splitk, d.tile, d.dma = splitk, tile, dma
     d.asym_pad = asym_pad
     d.split16 = 1 if split16 else 0      # a0 = hi, a1 = lo, w = pack_split3 ([N][3 c0])
+    d.f16_scale = _lib.ptr(f16_scale); d.lnp_out = _lib.ptr(lnp_out)
+    if lnf is not None:
+        part, eps, cs, dn = lnf
+        d.lnf_part = part.data_ptr(); d.lnf_npart = part.shape[0]; d.lnf_eps = float(eps)
+        d.lnf_cs = cs.data_ptr(); d.lnf_d = dn.data_ptr()
     if gn:      # [(acc int64 tensor [B,32,8,16] (zeroed), cpg, cbase)]
         d.gn_n = len(gn)
         for i, (acc, cpg, cbase) in enumerate(gn):
@@ -99,6 +105,16 @@ def gn_acc_sums(acc):
     s = (a[..., 0] + a[..., 1] / 2.0 ** 40).sum(-1)
     ss = (a[..., 2] + a[..., 3] / 2.0 ** 40).sum(-1)
     return s, ss
+
+
+def ln_fold_prep(w16, K, gamma, beta, bias=None):
+    """column terms of a LayerNorm-folding GEMM from the packed fp16 weights w16 [N, ldw >= K]: (cs, d) fp32 [N]"""
+    N = w16.shape[0]
+    cs = torch.empty((N,), dtype=torch.float32, device=w16.device)
+    dn = torch.empty((N,), dtype=torch.float32, device=w16.device)
+    _lib.check(_lib.load().sdmi_k_ln_fold_prep(w16.data_ptr(), N, K, w16.stride(0), gamma.data_ptr(), beta.data_ptr(),
+                                               _lib.ptr(bias), cs.data_ptr(), dn.data_ptr(), _s()))
+    return cs, dn
 
 
 def attention(q, k, vt, heads, nkv, scale):

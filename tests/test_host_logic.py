@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 9
+    assert lib.sdmi_abi_version() == 10
     for name in declared:
         assert hasattr(lib, name)
 
@@ -315,10 +315,16 @@ def test_committed_tuning_table_is_well_formed():
         assert len(r) == 11, r
         M, N, K, ksize, stride, up, mode, req, tile, splitk = (int(x) for x in r[:10])
         us = float(r[10])
-        assert M > 0 and N > 0 and K > 0 and K % 64 == 0 and ksize in (1, 3) and stride in (1, 2) and up in (0, 1) and mode in (0, 1, 2)
-        assert 0 <= tile < 22 and 1 <= splitk <= 16 and us > 0
+        # key ksize: 1 / 3 = the generic kernel, 11 = the split-fp16 dense GEMM family (gemm_split16.hip), 13 = the GroupNorm-folding
+        # halo conv (conv3halo_gn_kernel; tile 99 = "run it as two launches")
+        assert M > 0 and N > 0 and K > 0 and K % 64 == 0 and ksize in (1, 3, 11, 13) and stride in (1, 2) and up in (0, 1) and mode in (0, 1, 2)
+        assert (0 <= tile < 22 or (tile == 99 and ksize == 13)) and 1 <= splitk <= 16 and us > 0
+        if ksize == 11:
+            assert tile in (0, 1, 2, 4, 5, 8, 10) and mode == 0, r       # the tiles gemm_split16.hip instantiates
+        if ksize == 13:
+            assert tile in (14, 15, 16, 17, 99) and stride == 1 and up == 0, r
         if 14 <= tile <= 17:
-            assert ksize == 3 and stride == 1 and up == 0, r
+            assert ksize in (3, 13) and stride == 1 and up == 0, r
         if mode == 1:
             assert splitk == 1, r          # the GEGLU epilogue pairs columns inside a tile: never split
         key = tuple(r[:8])

@@ -769,3 +769,83 @@ def test_conv3_gn_fold(case):
                 residual=d(resid), out_f32=out2, splitk=splitk, tile=tile, fused_splitk=False)
         torch.cuda.synchronize()
         assert torch.equal(out, out2), float((out - out2).abs().max())
+
+
+@pytest.mark.parametrize('ptile,ctile', [(-1, -1), (5, 5), (4, 8), (1, 0), (10, 3)])
+@pytest.mark.parametrize('mode', ['heads', 'geglu', 'plain'])
+def test_layernorm_folded_into_consumer(mode, ptile, ctile):
+    """x = residual + a @ Wo^T + b (the token stream, attention.py:212-214), then Linear(LayerNorm(x)) -- q|k|v projection,
+    GEGLU or a plain Linear -- WITHOUT a LayerNorm launch: the producing GEMM stores fp16(gamma * x) and per-row {sum, sumsq}
+    partials, the consuming GEMM turns its accumulators into rstd * (acc - mean * cs) + d.  Against fp32 torch
+    (F.layer_norm -> F.linear) and against the two-launch path (producer -> layernorm kernel -> GEMM)."""
+    g = _g(77 + ptile + ctile)
+    B, ntok, Kp, C = 2, 1024, 256, 320                      # M = 2048 rows of C channels
+    M = B * ntok
+    a = (torch.randn(M, Kp, generator=g) * 0.7).half()
+    wo = (torch.randn(C, Kp, generator=g) / math.sqrt(Kp)).half()
+    bo = torch.randn(C, generator=g) * 0.1
+    resid = torch.randn(M, C, generator=g) * 1.5 + 0.3       # (a row mean that is not zero)
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    x = resid + a.float() @ wo.float().t() + bo
+    xn = F.layer_norm(x, (C,), gamma, beta, 1e-5)
+    d = lambda t: t.to(DEV)
+    x_dev = torch.empty(M, C, device=DEV); a16 = torch.empty(M, C, dtype=torch.float16, device=DEV)
+    part = torch.full((C // 32, M, 2), float('nan'), device=DEV)
+    K.igemm(d(a), d(wo), C, B, ntok, 1, ntok, 1, bias=d(bo), residual=d(resid), out_f32=x_dev, out_f16=a16, tile=ptile,
+            f16_scale=d(gamma), lnp_out=part)
+    torch.cuda.synchronize()
+    assert K.report('ln-fold producer x', x_dev, x, 2e-3) < 2e-3
+    # the partials: sums over 32-column blocks of the stored fp32 values
+    xs = x_dev.cpu().double().reshape(M, C // 32, 32)
+    assert torch.allclose(part[..., 0].cpu().double().t(), xs.sum(-1), rtol=1e-5, atol=1e-4)
+    assert torch.allclose(part[..., 1].cpu().double().t(), (xs * xs).sum(-1), rtol=1e-5, atol=1e-3)
+    assert torch.equal(a16.cpu(), (x_dev.cpu() * gamma).half())
+    # reference operand of the two-launch path
+    ln16 = K.layernorm(x_dev, d(gamma), d(beta))
+    if mode == 'plain':
+        N = 640
+        w = (torch.randn(N, C, generator=g) / math.sqrt(C)).half(); b = torch.randn(N, generator=g) * 0.1
+        ref = xn @ w.float().t() + b
+        cs, dn = K.ln_fold_prep(d(w), C, d(gamma), d(beta), d(b))
+        out = torch.empty(M, N, device=DEV); out2 = torch.empty(M, N, device=DEV)
+        K.igemm(a16, d(w), N, B, ntok, 1, ntok, 1, out_f32=out, tile=ctile, lnf=(part, 1e-5, cs, dn))
+        K.igemm(ln16, d(w), N, B, ntok, 1, ntok, 1, bias=d(b), out_f32=out2, tile=ctile)
+        torch.cuda.synchronize()
+        e1 = K.report(f'ln-fold plain folded   p{ptile} c{ctile}', out, ref, 6e-3)
+        e2 = K.report(f'ln-fold plain two-step p{ptile} c{ctile}', out2, ref, 6e-3)
+    elif mode == 'geglu':
+        N = 8 * C
+        w = torch.randn(N, C, generator=g) / math.sqrt(C); b = torch.randn(N, generator=g) * 0.1
+        y = xn @ w.half().float().t() + b
+        ref = y[:, :N // 2] * F.gelu(y[:, N // 2:])
+        wp, bp = K.pack_geglu(d(w), d(b))
+        cs, dn = K.ln_fold_prep(wp, C, d(gamma), d(beta), bp)
+        out = torch.empty(M, N // 2, dtype=torch.float16, device=DEV); out2 = torch.empty_like(out)
+        ct = ctile if ctile in (-1, 0, 3, 8) else 0
+        K.igemm(a16, wp, N, B, ntok, 1, ntok, 1, out_f16=out, mode=1, tile=ct, lnf=(part, 1e-5, cs, dn))
+        K.igemm(ln16, wp, N, B, ntok, 1, ntok, 1, bias=bp, out_f16=out2, mode=1, tile=ct)
+        torch.cuda.synchronize()
+        e1 = K.report(f'ln-fold geglu folded   p{ptile} c{ct}', out.float(), ref, 8e-3)
+        e2 = K.report(f'ln-fold geglu two-step p{ptile} c{ct}', out2.float(), ref, 8e-3)
+    else:
+        heads, dh = 8, C // 8
+        w = (torch.randn(3 * C, C, generator=g) / math.sqrt(C)).half()
+        ref = xn @ w.float().t()
+        cs, dn = K.ln_fold_prep(d(w), C, d(gamma), d(beta))
+        outs = []
+        for src, extra in ((a16, dict(lnf=(part, 1e-5, cs, dn))), (ln16, {})):
+            q = torch.empty(B * heads, ntok, dh, dtype=torch.float16, device=DEV); k = torch.empty_like(q)
+            vt = torch.empty(B * heads, dh, ntok, dtype=torch.float16, device=DEV)
+            K.igemm(src, d(w), 3 * C, B, ntok, 1, ntok, 1, mode=2, tile=ctile,
+                    heads=dict(segs=[(q, 0), (k, 0), (vt, 1)], heads=heads, dh=dh, ntok=ntok, ntok_pad=ntok, segC=C), **extra)
+            torch.cuda.synchronize()
+            qq = q.float().reshape(B, heads, ntok, dh).permute(0, 2, 1, 3).reshape(M, C)
+            kk = k.float().reshape(B, heads, ntok, dh).permute(0, 2, 1, 3).reshape(M, C)
+            vv = vt.float().reshape(B, heads, dh, ntok).permute(0, 3, 1, 2).reshape(M, C)
+            outs.append(torch.cat([qq, kk, vv], dim=1))
+        e1 = K.report(f'ln-fold heads folded   p{ptile} c{ctile}', outs[0], ref, 6e-3)
+        e2 = K.report(f'ln-fold heads two-step p{ptile} c{ctile}', outs[1], ref, 6e-3)
+    # the fold must not cost accuracy: the two-launch path's error level (both round one fp16 operand per element; the maxima of
+    # 1-3 M outputs scatter by +-20 %)
+    assert e1 < 8e-3 and e1 <= 1.5 * e2 + 5e-4, (e1, e2)

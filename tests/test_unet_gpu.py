@@ -226,6 +226,8 @@ def test_16_byte_epilogues_are_bit_identical(cfg_name, B, h, w, monkeypatch):
     cfg = CFGS[cfg_name]
     m, sd = _model(cfg_name, 0)
     x, t, ctx = make_inputs(cfg, B, h, w, seed=11)
+    # (the LayerNorm fold rides on the 16-byte epilogue and is NOT value-neutral: off for this comparison)
+    monkeypatch.setenv('SDMI_LN_FOLD', '0')
     monkeypatch.setenv('SDMI_EPI_VEC', '1')
     e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
     monkeypatch.setenv('SDMI_EPI_VEC', '0')
