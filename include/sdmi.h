@@ -203,7 +203,9 @@ typedef struct sdmi_igemm_desc {
                                            8 64x128/4/3, 9 128x128/8/3, 10 64x64/4/4, 11 128x256/8/2, 12 64x256/4/3, 13 256x64/4/3;
                                            halo-staged 3x3 conv (stride 1, pad 1, width 16/32/64, whole-row tiles):
                                            14 256x64/8/5, 15 256x128/8/3, 16 128x64/4/8, 17 128x128/4/5;
-                                           deep rings (generic): 18 64x64/4/8, 19 64x128/4/6, 20 128x64/4/6, 21 128x128/8/4 */
+                                           deep rings (generic): 18 64x64/4/8, 19 64x128/4/6, 20 128x64/4/6, 21 128x128/8/4;
+                                           22 64x160/5/5: five waves side by side (csrc/igemm5.hip; 1x1 / 3x3 stride 1-2, N % 160 == 0
+                                           for the auto choice): M = 8192, N = 320 -> 256 workgroups = one per CU */
   int32_t dma;                          /* -1 default, 0 register staging, 1 LDS-DMA */
   int32_t asym_pad;                     /* 3x3 only: 0 = zero pad 1 on every side; 1 = pad right/bottom only, i.e.
                                            F.pad(x,(0,1,0,1)) + conv(padding=0) of the VAE Downsample (model.py:72-76) */

@@ -168,7 +168,7 @@ struct IGemmParams {
 };
 
 constexpr int SDMI_TILE_TWO_LAUNCH = 99;   // (tuning table, GroupNorm-folding conv keys only) GroupNorm-apply launch + LDS-DMA conv
-constexpr int SDMI_NUM_TILES = 22;   // tile ids 0 .. 21 (14..17: halo-staged 3x3 conv), see kTiles in igemm.hip and include/sdmi.h
+constexpr int SDMI_NUM_TILES = 23;   // tile ids 0 .. 22 (14..17: halo-staged 3x3 conv, 22: five-wave 64 x 160), see kTiles in igemm.hip and include/sdmi.h
 struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes the tuning table's choice)
   int tile = -1;          // -1 auto (tuning table, then heuristic); else a tile id
   int dma = -1;           // -1 default, 0 register-staged loads, 1 global_load_lds

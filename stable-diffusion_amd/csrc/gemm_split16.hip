@@ -193,7 +193,7 @@ int launch_split16_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
-  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 1) && nsplit == 1;
+  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 0) && nsplit == 1;
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);

@@ -488,7 +488,9 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
-  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 1) && nsplit == 1;      // (read per launch: A/B knob, bit-identical results)
+  // (read per launch: A/B knob, bit-identical results.  Default off: same-box A/B, round 3, 6.24 vs 6.11 ms per UNet call -- the
+  // 640 workgroups' residual reads all land at kernel start, in front of the first operand tiles)
+  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 0) && nsplit == 1;
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
@@ -586,7 +588,10 @@ static const TileCfg kTiles[SDMI_NUM_TILES] = {
     {64, 128, 2, 2, 6},    // 19  1x2, 144 KB
     {128, 64, 2, 2, 6},    // 20  2x1, 144 KB
     {128, 128, 4, 2, 4},   // 21  8 waves, 1x2, 128 KB
+    // five waves side by side (igemm5.hip): N = 160 k, M = 8192 -> exactly one workgroup per CU
+    {64, 160, 1, 5, 5},    // 22  5 waves, 2x1 per wave, 140 KB
 };
+static inline bool tile_is5(int t) { return t == 22; }
 static inline bool tile_is_halo(int t) { return t >= 14 && t <= 17; }
 static inline bool tile_tn_even(int t) { return (kTiles[t].bn / kTiles[t].wn / 32) % 2 == 0; }
 
@@ -613,6 +618,7 @@ static int launch_tile(int tile, const IGemmParams& p, bool dma, int splitk, hip
     case 19: return launch_cfg<64, 128, 2, 2, 6>(p, dma, splitk, stream);
     case 20: return launch_cfg<128, 64, 2, 2, 6>(p, dma, splitk, stream);
     case 21: return launch_cfg<128, 128, 4, 2, 4>(p, dma, splitk, stream);
+    case 22: return launch_igemm5_tile(tile, p, splitk, stream);
     default: return fail("unknown igemm tile id");
   }
 }
@@ -694,6 +700,7 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
     if (tile_is_halo(t) && !halo_supported(p, c.bm)) continue;
     if (p.xf0 && (!tile_is_halo(t) || !halo_gn_supported(p, c.bm))) continue;     // GroupNorm-folding conv: halo tiles only
     if (p.split16 && !split16_tile_supported(t)) continue;                         // split-fp16 GEMM: its own instantiations
+    if (tile_is5(t) && (p.up || p.split16 || p.xf0 || p.N % c.bn != 0)) continue;   // five-wave tile: whole 160-column tiles, plain gathers
     // never chosen by any of the round-2 collection runs (profiles/tune_candidates_r02.txt): the 2-stage twins of the
     // 3-stage tiles, 128x128 / 256x128 with 2 stages, and the 64x256 / 256x64 4-wave tiles -- fewer candidates = more
     // samples per candidate
@@ -888,6 +895,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
                                           : (sk == 1 || (ws_ok && nkt / sk >= 4 && (halo || (sk != 5 && sk != 10)) &&
                                                          (!halo || (nkt / 9) % sk == 0)));
         if (split_ok && (p.mode != EPI_GEGLU || tile_tn_even(tt)) && (!halo || halo_supported(p, kTiles[tt].bm)) &&
+            (!tile_is5(tt) || (!p.up && !p.split16 && p.N % kTiles[tt].bn == 0)) &&
             (!gn_fold || (halo && halo_gn_supported(p, kTiles[tt].bm))) && (!p.split16 || split16_tile_supported(tt))) {
           tile = tt; splitk = sk;
         }

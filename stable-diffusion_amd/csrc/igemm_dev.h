@@ -698,6 +698,8 @@ static int epi_vec_ok(const IGemmParams& p) {
 
 }  // namespace
 
+// the five-wave 64 x 160 tile (igemm5.hip): tile id 22
+int launch_igemm5_tile(int tile, const IGemmParams& p, int splitk, hipStream_t stream);
 // halo-staged 3x3 convolution tiles (conv3halo.hip)
 bool halo_supported(const IGemmParams& p, int bm);
 int launch_halo_tile(int tile, const IGemmParams& p, int splitk, hipStream_t stream);

@@ -318,7 +318,7 @@ def test_committed_tuning_table_is_well_formed():
         # key ksize: 1 / 3 = the generic kernel, 11 = the split-fp16 dense GEMM family (gemm_split16.hip), 13 = the GroupNorm-folding
         # halo conv (conv3halo_gn_kernel; tile 99 = "run it as two launches")
         assert M > 0 and N > 0 and K > 0 and K % 64 == 0 and ksize in (1, 3, 11, 13) and stride in (1, 2) and up in (0, 1) and mode in (0, 1, 2)
-        assert (0 <= tile < 22 or (tile == 99 and ksize == 13)) and 1 <= splitk <= 16 and us > 0
+        assert (0 <= tile < 23 or (tile == 99 and ksize == 13)) and 1 <= splitk <= 16 and us > 0
         if ksize == 11:
             assert tile in (0, 1, 2, 4, 5, 8, 10) and mode == 0, r       # the tiles gemm_split16.hip instantiates
         if ksize == 13:

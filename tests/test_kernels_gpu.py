@@ -849,3 +849,67 @@ def test_layernorm_folded_into_consumer(mode, ptile, ctile):
     # the fold must not cost accuracy: the two-launch path's error level (both round one fp16 operand per element; the maxima of
     # 1-3 M outputs scatter by +-20 %)
     assert e1 < 8e-3 and e1 <= 1.5 * e2 + 5e-4, (e1, e2)
+
+
+FIVE_WAVE_CASES = [c for c in CONV_CASES if not c[9]]        # (the five-wave tile has no upsampling gather)
+
+
+@pytest.mark.parametrize('case', FIVE_WAVE_CASES, ids=[c[0] for c in FIVE_WAVE_CASES])
+@pytest.mark.parametrize('splitk', [1, 3])
+def test_igemm_five_wave_tile(case, splitk):
+    """tile 22 (csrc/igemm5.hip): 64 x 160, five waves side by side, operands dealt in 8-row octets over the (A | W) rows -- the
+    conv / linear cases of test_igemm_conv incl. masked taps, stride 2, concatenated sources, M and N tails, with and without
+    split-K (separate reduce)."""
+    name, B, Hin, Win, c0, c1, N, ksize, stride, up = case
+    g = _g(hash(name) % 1000 + 5)
+    Cin = c0 + c1
+    big = _rand16((B * Hin * Win, Cin), g)
+    a0 = big[:, :c0]
+    a1 = big[:, c0:] if c1 else None
+    w = _rand16((N, Cin, ksize, ksize), g, 1.0 / math.sqrt(Cin * ksize * ksize))
+    ref = _conv_ref(a0, a1, w, B, Hin, Win, ksize, stride, up)
+    Hout, Wout = ref.shape[2], ref.shape[3]
+    M = B * Hout * Wout
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    ref2 = _nhwc(ref) + bias[None] + rowvec.repeat_interleave(Hout * Wout, dim=0) + resid
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    nkt = (ksize * ksize * Cin) // 64
+    if splitk > 1 and (N % 4 or nkt < splitk):
+        pytest.skip('split-K needs N % 4 == 0 and enough k-tiles')
+    out32 = torch.full((M, N), float('nan'), device=DEV)
+    out16 = torch.full((M, N), float('nan'), device=DEV, dtype=torch.float16)
+    big_d = big.to(DEV)
+    K.igemm(big_d[:, :c0], wp, N, B, Hin, Win, Hout, Wout, ksize, stride, up, a1=big_d[:, c0:] if c1 else None,
+            bias=bias.to(DEV), rowvec=rowvec.to(DEV), residual=resid.to(DEV), out_f32=out32, out_f16=out16,
+            tile=22, splitk=splitk, fused_splitk=False)
+    torch.cuda.synchronize()
+    assert K.report(f'igemm5 {name} split{splitk} f32', out32, ref2, 2e-4) < 2e-4
+    assert K.report(f'igemm5 {name} split{splitk} f16', out16, ref2, 6e-3) < 6e-3
+
+
+@pytest.mark.parametrize('B,H,W,C,N,ksize', [(2, 64, 64, 320, 320, 3), (2, 64, 64, 320, 320, 1), (2, 32, 32, 640, 640, 3), (2, 64, 64, 320, 960, 1)])
+def test_igemm_five_wave_tile_sd_shapes(B, H, W, C, N, ksize):
+    """the shapes tile 22 is for (64x64 / 32x32 levels of SD v1), with the GroupNorm statistics of the output from the epilogue:
+    against tile 5 (64 x 64) on the same operands -- same products, per-k-tile accumulation order, so the outputs agree to the
+    last bits of an fp32 sum -- and the statistics against torch."""
+    g = _g(C + N + ksize)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, ksize, ksize), g, 1.0 / math.sqrt(C * ksize * ksize))
+    bias = torch.randn(N, generator=g)
+    resid = torch.randn(B * H * W, N, generator=g)
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    outs, accs = [], []
+    for tile in (22, 5):
+        out = torch.full((B * H * W, N), float('nan'), device=DEV)
+        acc = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+        gn = [(acc, N // 32, 0)] if N // 32 >= 2 else None
+        K.igemm(a.to(DEV), wp, N, B, H, W, H, W, ksize, bias=bias.to(DEV), residual=resid.to(DEV), out_f32=out, tile=tile, gn=gn)
+        torch.cuda.synchronize()
+        outs.append(out); accs.append(acc)
+    assert K.report(f'igemm5 sd M{B * H * W} N{N} K{C * ksize * ksize} vs tile 5', outs[0], outs[1], 1e-5) < 1e-5
+    s0, q0 = K.gn_acc_sums(accs[0])
+    xs = outs[0].cpu().double().reshape(B, H * W, 32, N // 32)
+    assert torch.allclose(s0, xs.sum(dim=(1, 3)), rtol=1e-6, atol=1e-3)
+    assert torch.allclose(q0, (xs * xs).sum(dim=(1, 3)), rtol=1e-6, atol=1e-2)
