@@ -148,10 +148,11 @@ def unet_latency_ms(unet, device, H=64, W=64, iters=10):
 
 
 def offline_traffic(kernel_class):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic_r01.json);
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic_rNN.json, the newest);
     PMC counters cannot be collected inside this process, so `roofline.traffic` is read from that committed pass."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'traffic_r02.json')))
+        path = next(p_ for p_ in (os.path.join(ROOT, 'profiles', f'traffic_r0{r}.json') for r in (3, 2)) if os.path.exists(p_))
+        d = json.load(open(path))
         k = d['kernels'].get(kernel_class)
         if k:
             return {'gbytes_per_launch': round((k['fetch_mb_x2'] + k['write_mb']) / 1e3, 4), 'source': d['source'],
@@ -171,7 +172,7 @@ def traffic_pass(out_json=None, keep_dir=None, also=None):
     import sqlite3
     import subprocess
     import tempfile
-    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r02.json')
+    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r03.json')
     work = keep_dir or tempfile.mkdtemp(prefix='sdmi_traffic_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     per = {}
@@ -192,7 +193,8 @@ def traffic_pass(out_json=None, keep_dir=None, also=None):
             con.close()
 
     def family(name):
-        for key, fam in (('igemm_kernel', 'igemm_family'), ('conv3halo_kernel', 'igemm_family'), ('attn', 'attention'),
+        for key, fam in (('igemm_kernel', 'igemm_family'), ('igemm5_kernel', 'igemm_family'), ('conv3halo_kernel', 'igemm_family'),
+                         ('conv3halo_gn_kernel', 'igemm_family'), ('gemm_split16_kernel', 'igemm_family'), ('attn', 'attention'),
                          ('splitk_reduce', 'splitk_reduce'), ('gn_apply', 'groupnorm'), ('gn_stats', 'groupnorm'),
                          ('layernorm', 'layernorm')):
             if key in name:
@@ -421,13 +423,13 @@ def main():
                 table.sort(key=lambda r: -r['ms'])
                 # The implicit-GEMM kernel is ONE template (csrc/igemm.hip) launched in several tile instantiations
                 # chosen per shape by the tuning table: the dominant kernel is that family; its instantiations are listed.
-                fam = [r for r in table if r['name'].startswith(('igemm', 'conv3halo'))]
-                dom = {'name': 'igemm_kernel / conv3halo_kernel (one GEMM core + epilogue, all tile instantiations)',
+                fam = [r for r in table if r['name'].startswith(('igemm', 'conv3halo', 'gemm_split16'))]
+                dom = {'name': 'igemm_kernel / conv3halo_kernel / gemm_split16_kernel (the GEMM family: one MFMA core + shared epilogue, all tile instantiations)',
                        'launches': sum(r['launches'] for r in fam), 'ms': sum(r['ms'] for r in fam),
                        'flops': sum(r['flops'] for r in fam), 'flops_exec': sum(r.get('flops_exec', r['flops']) for r in fam),
                        'bytes': sum(r['bytes'] for r in fam)}
                 top = fam[0]
-                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'conv3halo', 'attn'))]
+                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(('igemm', 'conv3halo', 'gemm_split16', 'attn'))]
                 # `flops` are ALGORITHMIC (2 x MACs of the reference's convs / linears); the 3-pass split-fp16
                 # 1x1 convs execute 3x theirs, which only `achieved_executed` / `frac_executed` count
                 ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12

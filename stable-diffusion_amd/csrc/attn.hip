@@ -390,6 +390,9 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const int ksw = (l31 >> 1) & 7;
   int cur = 0, nxt = NS - 1;
+  // Two waves share a SIMD's VALU issue by priority, then age: the second-dispatched half of an 8-wave workgroup loses every
+  // arbitration (MI355X_MICROARCH.md "two waves per SIMD", item 4).  One static s_setprio for that half, no per-phase flips.
+  if (NW == 8 && p.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int t = 0; t < nt; ++t) {
     if (ABL != 2) issue_tile(nxt);
     const unsigned char* Ks = smem + (ABL == 6 ? 0 : cur) * STAGE;
@@ -562,7 +565,10 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
   if (rc == 0 && range_check_enabled()) return range_scan("attention output", p.out, (int64_t)p.BH * p.nq * p.d, stream);
   return rc;
 }
-static int launch_attention_impl(const AttnParams& p, hipStream_t stream) {
+static int launch_attention_impl(const AttnParams& p_in, hipStream_t stream) {
+  AttnParams p = p_in;
+  static const int env_prio = getenv("SDMI_ATTN_PRIO") ? atoi(getenv("SDMI_ATTN_PRIO")) : 0;      // A/B knob (bit-identical)
+  p.prio = env_prio;
   SDMI_CHECK(p.BH > 0 && p.nq > 0 && p.nkv > 0 && p.heads > 0 && p.BH % p.heads == 0, "bad attention shape");
   SDMI_CHECK(p.nkv_pad % 8 == 0 && p.nkv_pad >= p.nkv, "nkv_pad must be a multiple of 8 and >= nkv");
   SDMI_CHECK(!p.causal || p.nq == p.nkv, "causal attention needs nq == nkv");
