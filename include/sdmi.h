@@ -240,6 +240,12 @@ int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* g
 /* q [BH,nq,d], k [BH,nkv,d], vt [BH,d,nkv_pad] fp16 -> out fp16 [BH/heads, nq, heads*d]; attention.py:178-192 */
 int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int nq, int nkv,
                      int nkv_pad, int d, float scale, void* stream);
+/* cross-attention with the to_q projection inside the kernel (csrc/attn_ctx.hip; attention.py:161,170-193): x fp16 [B*nq][C] token
+ * rows, wq fp16 [C][C] (rows = head * d + dd), k / vt as above with nkv <= 128 -> out fp16 [B, nq, C]; d in {40, 80, 160}.
+ * Optional LayerNorm fold (lnf_part != NULL): x = fp16(gamma * t), partials [C / 32][B * nq][2], cs / d from sdmi_k_ln_fold_prep. */
+int sdmi_k_attention_ctx(const void* x, const void* wq, const void* k, const void* vt, void* out, int BH, int heads, int nq,
+                         int nkv, int nkv_pad, int d, float scale, const float* lnf_part, float lnf_eps, const float* lnf_cs,
+                         const float* lnf_d, void* stream);
 /* same with a causal mask (query i attends to keys <= i; nq == nkv): CLIPTextModel's self-attention */
 int sdmi_k_attention_causal(const void* q, const void* k, const void* vt, void* out, int BH, int heads, int n, int n_pad,
                             int d, float scale, void* stream);

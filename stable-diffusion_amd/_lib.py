@@ -112,6 +112,8 @@ _SIGS = {
     'sdmi_k_pack_conv_out': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_split3': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_pack_geglu': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr]),
+    'sdmi_k_attention_ctx': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                       c_ptr, C.c_float, c_ptr, c_ptr, c_ptr]),
     'sdmi_k_ln_fold_prep': (C.c_int, [c_ptr, C.c_int, C.c_int, C.c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sdmi_image_to_uint8': (C.c_int, [c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_range_check': (C.c_int, [C.c_int]),

@@ -274,6 +274,15 @@ int sdmi_k_attention(const void* q, const void* k, const void* vt, void* out, in
   if (const char* e = getenv("SDMI_ATTN_NW")) a.nw = atoi(e);     // test / tuning knob
   return launch_attention(a, (hipStream_t)stream);
 }
+int sdmi_k_attention_ctx(const void* x, const void* wq, const void* k, const void* vt, void* out, int BH, int heads, int nq,
+                         int nkv, int nkv_pad, int d, float scale, const float* lnf_part, float lnf_eps, const float* lnf_cs,
+                         const float* lnf_d, void* stream) {
+  AttnCtxParams a;
+  a.x = (const f16*)x; a.wq = (const f16*)wq; a.k = (const f16*)k; a.vt = (const f16*)vt; a.out = (f16*)out;
+  a.BH = BH; a.heads = heads; a.nq = nq; a.nkv = nkv; a.nkv_pad = nkv_pad; a.d = d; a.C = heads * d; a.scale = scale;
+  if (lnf_part) { a.lnf_part = lnf_part; a.lnf_npart = a.C / 32; a.lnf_eps = lnf_eps; a.M = (BH / heads) * nq; a.lnf_cs = lnf_cs; a.lnf_d = lnf_d; }
+  return launch_attention_ctx(a, (hipStream_t)stream);
+}
 int64_t sdmi_k_groupnorm_ws_floats(int B, int HW) { (void)HW; return gn_acc_words(B) * 2; }   // int64 words, counted in floats
 int sdmi_k_groupnorm(const float* x0, const float* x1, int c0, int c1, int B, int HW, const float* gamma,
                      const float* beta, float eps, int silu, void* out_f16, float* out_f32, void* raw_f16, void* out_lo,

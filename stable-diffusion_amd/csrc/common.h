@@ -207,6 +207,22 @@ struct AttnParams {
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
 
+// Cross-attention with the query projection inside the kernel (attn_ctx.hip): out = softmax((x Wq^T) K^T scale) V over <= 128 cached keys
+struct AttnCtxParams {
+  const f16* x = nullptr;    // [B * nq][C] token rows: LayerNorm output, or fp16(gamma * t) with the LayerNorm fold below
+  const f16* wq = nullptr;   // [C][C] to_q weight, rows = output channels (head * d + dd)
+  const f16* k = nullptr;    // [BH][nkv][d]
+  const f16* vt = nullptr;   // [BH][d][nkv_pad]
+  f16* out = nullptr;        // [B][nq][heads * d]
+  int BH = 0, heads = 0, nq = 0, nkv = 0, nkv_pad = 0, d = 0, C = 0;
+  float scale = 1.f;
+  // optional LayerNorm fold (as IGemmParams::lnf_*): partials [lnf_npart = C / 32][M][2], M = B * nq rows
+  const float* lnf_part = nullptr; int lnf_npart = 0; float lnf_eps = 1e-5f; int M = 0;
+  const float* lnf_cs = nullptr; const float* lnf_d = nullptr;
+};
+bool attention_ctx_supported(int d, int C, int nkv);
+int launch_attention_ctx(const AttnCtxParams& p, hipStream_t stream);
+
 // GroupNorm(32) (+SiLU) over fp32 NHWC, channel-concat of two sources, fp16 or fp32 output
 struct GroupNormParams {
   const float* x0 = nullptr; const float* x1 = nullptr; int c0 = 0, c1 = 0;

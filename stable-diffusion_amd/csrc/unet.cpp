@@ -452,6 +452,10 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
 struct Fwd : FwdBase {
   UNet* u; int Lctx;
   bool ln_fold_on = false;      // this call folds LayerNorms into their consuming GEMMs (UNet::ln_fold_; read per call: A/B knobs)
+  // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
+  // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
+  bool fuse_ctx_q = false;
+  int fuse_ctx_maxd = 160;      // ... for head dims up to this (SDMI_ATTN_CTX_MAXD)
   float* emb_all = nullptr;     // [B][emb_total] (emb_ld = emb_total), or one row of the timestep table shared by every sample (emb_ld = 0)
   int emb_ld = 0;
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
@@ -604,15 +608,22 @@ struct Fwd : FwdBase {
         gemm(p);
       }
       // x = attn2(norm2(x), context) + x                           attention.py:213
-      {
+      if (ctx16) context_kv(L, d);
+      if (fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx)) {
+        // to_q inside the attention kernel (attn_ctx.hip): one launch for q = norm2(x) Wq^T and softmax(q K^T) V
+        AttnCtxParams a;
+        a.x = ln; a.wq = T.wq2; a.k = T.ck; a.vt = T.cvt; a.out = ao;
+        a.BH = B * L.heads; a.heads = L.heads; a.nq = N; a.nkv = Lctx; a.nkv_pad = Lp; a.d = L.dh; a.C = C; a.scale = scale;
+        if (fold_ln) { a.lnf_part = lnp; a.lnf_npart = C / 32; a.lnf_eps = 1e-5f; a.M = M; a.lnf_cs = T.lnf[2]; a.lnf_d = T.lnf[3]; }
+        if (!dry && !rc) ok(launch_attention_ctx(a, s));
+      } else {
         IGemmParams p = dense(ln, M, C, T.wq2, C, N);
         p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_kind[0] = 0;
         p.heads = L.heads; p.dh = L.dh; p.ntok = N; p.ntok_pad = Np; p.segC = C; p.splitk = 1;
         fold_in(p, T.lnf[2], T.lnf[3]);
         gemm(p);
+        attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);
       }
-      if (ctx16) context_kv(L, d);
-      attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);
       {
         IGemmParams p = dense(ao, M, C, T.wo2, C, N);
         p.bias = T.bo2; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
@@ -798,6 +809,9 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     // (both knobs are read per call -- the tests flip them between two forwards; the row statistics ride on the 16-byte epilogue)
     const char* e_fold = getenv("SDMI_LN_FOLD"); const char* e_vec = getenv("SDMI_EPI_VEC");
     f.ln_fold_on = (e_fold ? atoi(e_fold) != 0 : ln_fold_) && !(e_vec && atoi(e_vec) == 0);
+    const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
+    f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
+    if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);
   }
   if (side_stream_ && !dry && !prof_enabled()) {      // (the per-launch profiler times launches on one stream)
     if (!side_) {

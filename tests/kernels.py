@@ -107,6 +107,20 @@ def gn_acc_sums(acc):
     return s, ss
 
 
+def attention_ctx(x16, wq16, k, vt, heads, nkv, scale, lnf=None):
+    """x16 [B*nq, C] fp16, wq16 [C, C] fp16, k [BH, nkv, d], vt [BH, d, nkv_pad] -> [B, nq, C] fp16 (to_q inside the kernel);
+    lnf = (partials [C/32, B*nq, 2], eps, cs, d): LayerNorm fold"""
+    BH, _, d = k.shape
+    B = BH // heads
+    nq = x16.shape[0] // B
+    out = torch.empty((B, nq, heads * d), dtype=torch.float16, device=x16.device)
+    part, eps, cs, dn = lnf if lnf is not None else (None, 1e-5, None, None)
+    _lib.check(_lib.load().sdmi_k_attention_ctx(x16.data_ptr(), wq16.data_ptr(), k.data_ptr(), vt.data_ptr(), out.data_ptr(), BH, heads,
+                                                nq, nkv, vt.shape[2], d, float(scale), _lib.ptr(part), float(eps), _lib.ptr(cs),
+                                                _lib.ptr(dn), _s()))
+    return out
+
+
 def ln_fold_prep(w16, K, gamma, beta, bias=None):
     """column terms of a LayerNorm-folding GEMM from the packed fp16 weights w16 [N, ldw >= K]: (cs, d) fp32 [N]"""
     N = w16.shape[0]

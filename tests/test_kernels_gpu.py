@@ -913,3 +913,52 @@ def test_igemm_five_wave_tile_sd_shapes(B, H, W, C, N, ksize):
     xs = outs[0].cpu().double().reshape(B, H * W, 32, N // 32)
     assert torch.allclose(s0, xs.sum(dim=(1, 3)), rtol=1e-6, atol=1e-3)
     assert torch.allclose(q0, (xs * xs).sum(dim=(1, 3)), rtol=1e-6, atol=1e-2)
+
+
+@pytest.mark.parametrize('d,heads,nq,nkv,B', [(40, 8, 4096, 77, 2), (80, 8, 1024, 77, 2), (160, 8, 256, 77, 2), (160, 8, 64, 77, 2),
+                                              (40, 8, 100, 77, 1), (80, 8, 64, 128, 1), (160, 8, 33, 5, 3), (40, 8, 256, 96, 2)])
+@pytest.mark.parametrize('fold', [False, True])
+def test_attention_ctx_fused_q(d, heads, nq, nkv, B, fold, monkeypatch):
+    """Cross-attention with the to_q projection inside the kernel (csrc/attn_ctx.hip; attention.py:161,170-193):
+    out = softmax((LN(t) Wq^T) K^T d^-0.5) V over the cached context keys, against fp32 torch and against the two-launch path
+    (to_q GEMM with the per-head scatter -> flash attention); with and without the LayerNorm fold (x = fp16(gamma t) + row partials)."""
+    g = _g(d + nq + nkv + (7 if fold else 0))
+    C = heads * d
+    M = B * nq
+    t = torch.randn(M, C, generator=g) * 1.2 + 0.2
+    gamma = 1 + 0.2 * torch.randn(C, generator=g)
+    beta = 0.1 * torch.randn(C, generator=g)
+    wq = (torch.randn(C, C, generator=g) / math.sqrt(C)).half()
+    nkv_pad = (nkv + 7) // 8 * 8
+    k = (torch.randn(B * heads, nkv, d, generator=g) * 0.8).half()
+    v = (torch.randn(B * heads, nkv, d, generator=g)).half()
+    vt = torch.zeros(B * heads, d, nkv_pad, dtype=torch.float16)
+    vt[:, :, :nkv] = v.transpose(1, 2)
+    scale = d ** -0.5
+    xn = F.layer_norm(t, (C,), gamma, beta, 1e-5)
+    q = (xn @ wq.float().t()).reshape(B, nq, heads, d).permute(0, 2, 1, 3).reshape(B * heads, nq, d)
+    att = torch.softmax(q @ k.float().transpose(1, 2) * scale, dim=-1) @ v.float()
+    ref = att.reshape(B, heads, nq, d).permute(0, 2, 1, 3).reshape(B, nq, C)
+    dv = lambda z: z.to(DEV)
+    ln16 = K.layernorm(dv(t), dv(gamma), dv(beta))
+    if fold:
+        if C > 640:
+            pytest.skip('the fold is taken for C <= 640 (20 partials)')
+        # the producer's side, emulated: fp16(gamma * t) and {sum, sumsq} per 32-column block
+        x16 = (t * gamma).half()
+        tb = t.double().reshape(M, C // 32, 32)
+        part = torch.stack([tb.sum(-1), (tb * tb).sum(-1)], dim=-1).permute(1, 0, 2).float().contiguous()
+        cs, dn = K.ln_fold_prep(dv(wq), C, dv(gamma), dv(beta))
+        out = K.attention_ctx(dv(x16), dv(wq), dv(k), dv(vt), heads, nkv, scale, lnf=(dv(part), 1e-5, cs, dn))
+    else:
+        out = K.attention_ctx(ln16, dv(wq), dv(k), dv(vt), heads, nkv, scale)
+    # the two-launch path on the same operands
+    qd = torch.empty(B * heads, nq, d, dtype=torch.float16, device=DEV)
+    K.igemm(ln16, dv(wq), C, B, nq, 1, nq, 1, mode=2,
+            heads=dict(segs=[(qd, 0)], heads=heads, dh=d, ntok=nq, ntok_pad=(nq + 7) // 8 * 8, segC=C))
+    out2 = K.attention(qd, dv(k), dv(vt), heads, nkv, scale)
+    torch.cuda.synchronize()
+    e1 = K.report(f'attn_ctx fused d{d} nq{nq} nkv{nkv} B{B} fold{int(fold)}', out, ref, 4e-3)
+    e2 = K.report(f'attn_ctx two-launch d{d} nq{nq} nkv{nkv} B{B}', out2, ref, 4e-3)
+    assert not torch.isnan(out).any()
+    assert e1 < 4e-3 and e1 <= 1.5 * e2 + 3e-4, (e1, e2)
