@@ -15,6 +15,8 @@
 //   * V is consumed transposed ([d][key], key-contiguous) -- the QKV projection epilogue (igemm EPI_HEADS)
 //     writes it that way, so no transpose happens here.
 //   * fp32 scores, max, sum and output accumulation; exp via v_exp_f32 on log2e-prescaled scores.
+#include <type_traits>
+
 #include "common.h"
 #include "prof.h"
 
@@ -511,6 +513,257 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+// ---- ping-pong variant of attn_dma_kernel for 8-wave workgroups (two waves per SIMD) ------------------------------------------
+// Same arithmetic, operand layouts and LDS-DMA ring as attn_dma_kernel -- per wave the very same instruction sequence on the same
+// values, so the results are bit-identical -- but the two waves of a SIMD no longer run in lock-step.  attn_dma_kernel has one
+// barrier per key tile: all eight waves do QK^T (matrix pipe), then all do the softmax (VALU: 32 v_exp_f32 + 16 cvt + 16 max3 + 20
+// fma per lane and tile), then all do PV (matrix pipe) -- the ablations of round 2 (profiles/attn_variants_r02.txt) show every
+// ingredient costing exactly its own pipe time: zero overlap between the two waves that share a SIMD's matrix pipe and VALU issue.
+// Here a key tile is TWO steps with a barrier each, and the halves of the workgroup (waves 0-3 / 4-7: wave i and i + 4 share a
+// SIMD) run them in opposite order:
+//     step 2t     : half A  [PV(t-1), QK^T(t)]  (14 MFMAs)     half B  softmax(t-1)          (VALU)
+//     step 2t + 1 : half A  softmax(t)          (VALU)          half B  [PV(t-1), QK^T(t)]    (14 MFMAs)
+// so each SIMD always has one wave in its matrix block and one in its VALU block (MI355X_MICROARCH.md "two waves per SIMD": the
+// matrix pipe and the VALU of a SIMD run concurrently for two different waves; a rendezvous pays when the paired intervals are
+// complementary).  P(t) stays in registers from softmax(t) to PV(t) one step later; tile t's ring slot is read until half B's
+// PV(t) at step 2t + 3, so the ring runs NS - 2 tiles ahead instead of NS - 1.
+template <int D, int NS>
+__global__ void __launch_bounds__(512) attn_pp_kernel(const AttnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr int NW = 8;
+  constexpr int DKS = (D + 15) / 16;
+  constexpr int DVT = (D + 31) / 32;
+  constexpr int NCH = (D + 63) / 64;
+  constexpr int KROWS = NCH * 64, VROWS = DVT * 32;
+  constexpr int STAGE = (KROWS + VROWS) * 128;
+  constexpr bool ONES = VROWS > D;
+  constexpr int PK = NCH * 8, PV = ONES ? D / 8 : DVT * 4, PT = PK + PV;
+  static_assert(D % 8 == 0, "a DMA piece is 8 rows");
+  constexpr int PPW = (PT + NW - 1) / NW;
+  static_assert(NS >= 4 && NS * STAGE <= 160 * 1024, "LDS budget (the ring runs NS - 2 tiles ahead)");
+
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;                         // half of the workgroup: 0 = matrix block on even steps, 1 = on odd steps
+  const int l31 = lane & 31, lg = lane >> 5;
+  int bh, qt;
+  head_of_block(bh, qt);
+  const int q0 = qt * (32 * NW) + wave * 32;
+  const f16* Qg = p.q + (size_t)bh * p.nq * D;
+  constexpr int OOB = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rsrc_k =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.k + (size_t)bh * p.nkv * D), 0, p.nkv * D * 2, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc_v =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.vt + (size_t)bh * D * p.nkv_pad), 0, D * p.nkv_pad * 2, 0x00020000);
+
+  f16x8 qf[DKS];
+#pragma unroll
+  for (int ks = 0; ks < DKS; ++ks) {
+    const int dcol = ks * 16 + lg * 8;
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (q0 + l31 < p.nq && dcol < D) v = *(const f16x8*)(Qg + (size_t)(q0 + l31) * D + dcol);
+    qf[ks] = v;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the Q fragments are register loads: drained before any LDS-DMA is in flight)
+
+  int pv_off[PPW], pv_step[PPW], pv_row[PPW];
+  bool pv_isk[PPW];
+#pragma unroll
+  for (int j = 0; j < PPW; ++j) {
+    const int q = min(wave + j * NW, PT - 1);
+    const int r8 = lane >> 3, cp = lane & 7;
+    if (q < PK) {
+      const int c = q >> 3, row = (q & 7) * 8 + r8;
+      const int key = (row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1);
+      const int gch = cp ^ ((row >> 1) & 7);
+      pv_off[j] = key * (D * 2) + c * 128 + gch * 16;
+      pv_step[j] = KVT * D * 2;
+      pv_row[j] = c * 64 + (q & 7) * 8;
+      pv_isk[j] = true;
+    } else {
+      const int qv = q - PK, dt = qv >> 2, row = (qv & 3) * 8 + r8;
+      const int d = dt * 32 + row;
+      const int gch = cp ^ ((row >> 1) & 7);
+      pv_off[j] = d < D ? d * (p.nkv_pad * 2) + gch * 16 : OOB;
+      pv_step[j] = d < D ? KVT * 2 : 0;
+      pv_row[j] = KROWS + dt * 32 + (qv & 3) * 8;
+      pv_isk[j] = false;
+    }
+  }
+  auto issue_tile = [&](int stage) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+      auto dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE + pv_row[j] * 128);
+      if (pv_isk[j]) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, dst, 16, pv_off[j], 0, 0, 0);
+      else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, dst, 16, pv_off[j], 0, 0, 0);
+      pv_off[j] += pv_step[j];
+    }
+  };
+
+  f32x16 o[DVT];
+#pragma unroll
+  for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+  float m_run = -1e30f, l_run = 0.f;
+  if (ONES) {
+    for (int e = tid; e < NS * (VROWS - D) * 8; e += NW * 64) {
+      const int st = e / ((VROWS - D) * 8), rc = e - st * ((VROWS - D) * 8), row = D + (rc >> 3);
+      const unsigned one2 = row == D ? 0x3C003C00u : 0u;
+      *(u32x4*)(smem + st * STAGE + (KROWS + row) * 128 + (rc & 7) * 16) = u32x4{one2, one2, one2, one2};
+    }
+  }
+  const float sc = p.scale * 1.4426950408889634f;
+  const int nt = (p.nkv + KVT - 1) / KVT;
+  const int ksw = (l31 >> 1) & 7;
+
+  // the three blocks of a tile (the same code as attn_dma_kernel's loop body, cut at the two hand-overs)
+  f32x16 s[KVT / 32];                                // scores, then fp32 probabilities of the tile in flight
+  f16x8 pf[KVT / 32][2];                             // ... as fp16 B fragments, from softmax(t) to PV(t)
+  auto qk = [&](int t) __attribute__((always_inline)) {
+    const unsigned char* Ks = smem + (t % NS) * STAGE;
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kvb][r] = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < DKS; ++ks) {
+        const unsigned char* kp = Ks + ((ks >> 2) * 64 + kvb * 32 + l31) * 128 + ((((ks & 3) * 2 + lg) ^ ksw) << 4);
+        const f16x8 a = *(const f16x8*)kp;
+        s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
+      }
+    }
+  };
+  auto softmax = [&](int t) __attribute__((always_inline)) {
+    const int kv0 = t * KVT;
+    if (kv0 + KVT > p.nkv) {
+      asm volatile("; masked tile" ::: "memory");
+#pragma unroll
+      for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kv = kv0 + kvb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * lg + 16 * (r >> 3);
+          if (kv >= p.nkv) s[kvb][r] = -1e30f;
+        }
+    }
+    float mx = -1e30f;
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kvb][r]);
+    mx = max_across_halves(mx);
+    const float m_new = fmaxf(m_run, mx * sc);
+    if (__any(m_new > m_run)) {
+      asm volatile("; rescale" ::: "memory");
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+      m_run = m_new;
+      if (!ONES) l_run *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+    }
+    f32x2 psum2 = {0.f, 0.f};
+    const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const f32x2 sv = {s[kvb][r], s[kvb][r + 1]};
+        const f32x2 e = __builtin_elementwise_fma(sv, sc2, nm2);
+        const f32x2 pv = {__builtin_amdgcn_exp2f(e[0]), __builtin_amdgcn_exp2f(e[1])};
+        s[kvb][r] = pv[0];
+        s[kvb][r + 1] = pv[1];
+        if (!ONES) psum2 += pv;
+      }
+    if (!ONES) l_run += psum2[0] + psum2[1];
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) pf[kvb][s2][e] = (f16)s[kvb][8 * s2 + e];
+  };
+  auto pvmul = [&](int t) __attribute__((always_inline)) {
+    const unsigned char* Vs = smem + (t % NS) * STAGE + KROWS * 128;
+#pragma unroll
+    for (int kvb = 0; kvb < KVT / 32; ++kvb)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ch = 4 * kvb + 2 * s2;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt) {
+          const f16x8 a = *(const f16x8*)(Vs + (dt * 32 + l31) * 128 + (((ch + lg) ^ ksw) << 4));
+          o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, pf[kvb][s2], o[dt], 0, 0, 0);
+        }
+      }
+  };
+
+  // ring: tiles 0 .. NS - 3 up front; tile t + NS - 2 is requested at step 2 t (its slot held tile t - 2, last read by half B's
+  // PV(t - 2) at step 2 t - 1); tile t must have landed for everybody when step 2 t begins
+#pragma unroll
+  for (int s2 = 0; s2 < NS - 2; ++s2) issue_tile(s2);
+  wait_dma<PPW*(NS - 3)>();                          // tile 0
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // One loop per half, chosen once: inside it the blocks follow each other in a fixed order and update s / pf / o in place (a
+  // single loop that picks the block by the parity of a step counter made the compiler copy the 80 accumulator registers around
+  // at every join: 184 v_mov per step, 145 us instead of 81).  Both halves execute the same barriers: two per key tile.
+  auto run_half = [&](auto grp_c) __attribute__((always_inline)) {
+    constexpr int G = decltype(grp_c)::value;
+    for (int t = 0; t <= nt; ++t) {
+      issue_tile((t + NS - 2) % NS);                 // (tiles past nt read out of range: zeros, never consumed)
+      if constexpr (G == 0) {                        // step 2 t
+        if (t >= 1) pvmul(t - 1);
+        if (t < nt) qk(t);
+      } else {
+        if (t >= 1) softmax(t - 1);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if constexpr (G == 0) {                        // step 2 t + 1
+        if (t < nt) softmax(t);
+      } else {
+        if (t >= 1) pvmul(t - 1);
+        if (t < nt) qk(t);
+      }
+      wait_dma<PPW*(NS - 3)>();                      // tile t + 1, needed from the next step on, has landed for this wave
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    }
+  };
+  if (grp == 0) run_half(std::integral_constant<int, 0>{});
+  else run_half(std::integral_constant<int, 1>{});
+  wait_dma<0>();
+
+  float l_tot;
+  if (ONES) {
+    constexpr int rl = D % 32, r_l = (rl & 3) + 4 * (rl >> 3), lg_l = (rl >> 2) & 1;
+    float a = o[D / 32][r_l], b = a;
+    swap_halves(a, b);
+    l_tot = lg_l == 0 ? a : b;
+  } else {
+    l_tot = sum_across_halves(l_run);
+  }
+  const float inv = 1.0f / l_tot;
+  const int q = q0 + l31;
+  if (q < p.nq) {
+    const int b = bh / p.heads, head = bh - b * p.heads;
+    f16* orow = p.out + ((size_t)b * p.nq + q) * ((size_t)p.heads * D) + (size_t)head * D;
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int dd = dt * 32 + 8 * r4 + 4 * lg;
+        if (dd < D) {
+          f16x4 v = {(f16)(o[dt][r4 * 4 + 0] * inv), (f16)(o[dt][r4 * 4 + 1] * inv), (f16)(o[dt][r4 * 4 + 2] * inv),
+                     (f16)(o[dt][r4 * 4 + 3] * inv)};
+          SDMI_ST(f16x4, orow + dd, v);
+        }
+      }
+  }
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 template <int D>
 int launch_d(const AttnParams& p, hipStream_t stream) {
   // Long sequences (> 1024 queries): 8 waves share each K/V tile.  Short ones (the 32x32 / 16x16 / 8x8 levels) are
@@ -544,6 +797,8 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
           default: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 6>), grid, dim3(512), 0, stream, p); break;
         }
       }
+    } else if (nw == 8 && p.pingpong && DNS >= 4) {
+      if constexpr (DNS >= 4) hipLaunchKernelGGL((attn_pp_kernel<D, DNS>), grid, dim3(512), 0, stream, p);
     } else if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
     else if (nw == 4) hipLaunchKernelGGL((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);
@@ -569,6 +824,8 @@ static int launch_attention_impl(const AttnParams& p_in, hipStream_t stream) {
   AttnParams p = p_in;
   static const int env_prio = getenv("SDMI_ATTN_PRIO") ? atoi(getenv("SDMI_ATTN_PRIO")) : 0;      // A/B knob (bit-identical)
   p.prio = env_prio;
+  const char* e_pp = getenv("SDMI_ATTN_PP");          // (read per launch: the tests flip it) 8-wave launches on attn_pp_kernel
+  p.pingpong = e_pp ? atoi(e_pp) : 0;
   SDMI_CHECK(p.BH > 0 && p.nq > 0 && p.nkv > 0 && p.heads > 0 && p.BH % p.heads == 0, "bad attention shape");
   SDMI_CHECK(p.nkv_pad % 8 == 0 && p.nkv_pad >= p.nkv, "nkv_pad must be a multiple of 8 and >= nkv");
   SDMI_CHECK(!p.causal || p.nq == p.nkv, "causal attention needs nq == nkv");

@@ -204,6 +204,7 @@ struct AttnParams {
   int nw = 0;                // waves per workgroup (0 = auto): each wave owns 32 queries
   int causal = 0;            // 1: key j attends only to queries i >= j (CLIP text model); needs nq == nkv
   int prio = 0;              // launcher (SDMI_ATTN_PRIO=1): s_setprio 1 for the second-dispatched half of an 8-wave workgroup
+  int pingpong = 0;          // launcher (SDMI_ATTN_PP): 8-wave launches on attn_pp_kernel (the halves of a workgroup alternate matrix / VALU blocks)
 };
 int launch_attention(const AttnParams& p, hipStream_t stream);
 

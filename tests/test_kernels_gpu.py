@@ -962,3 +962,30 @@ def test_attention_ctx_fused_q(d, heads, nq, nkv, B, fold, monkeypatch):
     e2 = K.report(f'attn_ctx two-launch d{d} nq{nq} nkv{nkv} B{B}', out2, ref, 4e-3)
     assert not torch.isnan(out).any()
     assert e1 < 4e-3 and e1 <= 1.5 * e2 + 3e-4, (e1, e2)
+
+
+@pytest.mark.parametrize('d,heads,nq,nkv', [(40, 8, 4096, 4096), (40, 8, 4096, 4000), (80, 8, 1024, 1024), (64, 4, 512, 77), (40, 8, 2304, 2304),
+                                            (128, 2, 300, 130), (32, 4, 256, 64)])
+def test_attention_pingpong_is_bit_identical(d, heads, nq, nkv, monkeypatch):
+    """attn_pp_kernel (SDMI_ATTN_PP=1): the halves of an 8-wave workgroup alternate their matrix and VALU blocks instead of running
+    in lock-step -- per wave the same instructions on the same values as attn_dma_kernel, so the output must not change by one bit
+    (and both are within the usual tolerance of fp32 torch)."""
+    g = _g(d + nq + nkv)
+    B = 2
+    q = (torch.randn(B * heads, nq, d, generator=g)).half()
+    k = (torch.randn(B * heads, nkv, d, generator=g)).half()
+    v = (torch.randn(B * heads, nkv, d, generator=g)).half()
+    nkv_pad = (nkv + 7) // 8 * 8
+    vt = torch.zeros(B * heads, d, nkv_pad, dtype=torch.float16)
+    vt[:, :, :nkv] = v.transpose(1, 2)
+    scale = d ** -0.5
+    ref = (torch.softmax(q.float() @ k.float().transpose(1, 2) * scale, dim=-1) @ v.float())
+    ref = ref.reshape(B, heads, nq, d).permute(0, 2, 1, 3).reshape(B, nq, heads * d)
+    monkeypatch.setenv('SDMI_ATTN_NW', '8')
+    monkeypatch.setenv('SDMI_ATTN_PP', '0')
+    o0 = K.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, nkv, scale).clone()
+    monkeypatch.setenv('SDMI_ATTN_PP', '1')
+    o1 = K.attention(q.to(DEV), k.to(DEV), vt.to(DEV), heads, nkv, scale).clone()
+    torch.cuda.synchronize()
+    assert K.report(f'attention ping-pong d{d} nq{nq} nkv{nkv}', o1, ref, 3e-3) < 3e-3
+    assert torch.equal(o0, o1), float((o0.float() - o1.float()).abs().max())
