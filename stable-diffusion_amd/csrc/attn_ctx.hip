@@ -129,11 +129,11 @@ __global__ void __launch_bounds__(NW * 64) attn_ctx_kernel(const AttnCtxParams p
     const int m = b * p.nq + min(q_lane, p.nq - 1);
     const float2* src = (const float2*)p.lnf_part + m;
     float sx = 0.f, sq = 0.f;
-    float2 pv[LNF_MAXP];
+    float2 pv[20];
 #pragma unroll
-    for (int j = 0; j < LNF_MAXP; ++j) pv[j] = src[(size_t)min(j, p.lnf_npart - 1) * p.M];
+    for (int j = 0; j < 20; ++j) pv[j] = src[(size_t)min(j, p.lnf_npart - 1) * p.M];
 #pragma unroll
-    for (int j = 0; j < LNF_MAXP; ++j)
+    for (int j = 0; j < 20; ++j)
       if (j < p.lnf_npart) { sx += pv[j].x; sq += pv[j].y; }
     const float inv_c = 1.0f / (32.0f * (float)p.lnf_npart);
     mean = sx * inv_c;

@@ -136,7 +136,6 @@ struct IGemmParams {
 #endif
   int splitk_fused = 0;                                // set by the launcher
   int epi_vec = 0;                                     // set by the launcher: 16-byte epilogue (pointer / pitch alignment checked there)
-  int epi_pre = 0;                                     // set by the launcher: residual quads of that epilogue fetched in the kernel prologue (small tiles)
   int tile_n_fastest = 0;                              // set by the launcher: tile numbering inside an XCD's range
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)
   // optional (plain mode): GroupNorm(32) statistics of the finished output for up to two consuming GroupNorms -- the

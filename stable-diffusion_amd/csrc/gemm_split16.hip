@@ -56,8 +56,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) gemm_split16_kernel(con
 
   const int tid = threadIdx.x;
   SDMI_STAMP(dbg_t0);
-  f32x4 pre_res[4];                      // residual quads of the epilogue, requested first of all (igemm_dev.h epi_prefetch_residual)
-  const bool pre_ok = p.epi_pre && epi_prefetch_residual<BM, BN, WARPS_M, WARPS_N>(p, m0, n0, pre_res);
   const int lane = tid & 63, wave = tid >> 6;
   const int cpos = tid & 7, lrow = tid >> 3;
   const int gch = cpos ^ ((lrow >> 1) & 7);      // global chunk that lands at (row, cpos)
@@ -171,8 +169,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) gemm_split16_kernel(con
   }
   wait_vmcnt<0>();
   SDMI_STAMP(dbg_t2);
-  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem, 0.f, 1.f,
-                                                             pre_ok ? pre_res : nullptr);
+  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem);
 #ifdef SDMI_IGEMM_TIMING
   if (p.dbg_times && tid == 0) {
     long long* d = p.dbg_times + 6 * (size_t)blockIdx.x;
@@ -193,7 +190,6 @@ int launch_split16_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
-  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 0) && nsplit == 1;
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);

@@ -84,9 +84,6 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
   float lnf_mean = 0.f, lnf_rstd = 1.f;
   const bool lnf_mine = p.lnf_part != nullptr && tid < BM;
   if (lnf_mine) lnf_request(p, min(m0 + tid, p.M - 1), lnf_pv);
-  // ... and so are the residual quads of the epilogue (small tiles only, see epi_prefetch_residual)
-  f32x4 pre_res[4];
-  const bool pre_ok = p.epi_pre && epi_prefetch_residual<BM, BN, WARPS_M, WARPS_N>(p, m0, n0, pre_res);
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int cpos = tid & 7;                      // chunk position inside the LDS row
@@ -351,8 +348,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 
   // ---- epilogue ------------------------------------------------------------------------------------
   SDMI_STAMP(dbg_t2);
-  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem, lnf_mean, lnf_rstd,
-                                                             pre_ok ? pre_res : nullptr);
+  igemm_epilogue<BM, BN, WARPS_M, WARPS_N, NS * STAGE_BYTES>(p, acc, m0, n0, split, tile_m, tile_n, smem, lnf_mean, lnf_rstd);
 #ifdef SDMI_IGEMM_TIMING
   if (p.dbg_times && tid == 0) {        // (where a workgroup's time goes; blocks that return early in the epilogue are not stamped)
     long long* d = p.dbg_times + 6 * (size_t)blockIdx.x;      // d[3] = after the output stores (written inside the epilogue)
@@ -488,9 +484,6 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
-  // (read per launch: A/B knob, bit-identical results.  Default off: same-box A/B, round 3, 6.24 vs 6.11 ms per UNet call -- the
-  // 640 workgroups' residual reads all land at kernel start, in front of the first operand tiles)
-  q.epi_pre = env_int("SDMI_EPI_PREFETCH", 0) && nsplit == 1;
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
@@ -834,8 +827,8 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
                "LayerNorm row statistics: plain mode, fp32 + fp16 outputs, no split-K, M / N / rows per sample multiples of 64, 16-byte aligned rows");
   if (p.lnf_part)                      // consumer that folds the LayerNorm of its A rows (IGemmParams::lnf_*)
     SDMI_CHECK(p.ksize == 1 && p.c1 == 0 && p.c2 == 0 && !p.split16 && p.lnf_npart * 32 == p.K && p.lnf_cs && p.lnf_d && !p.bias &&
-                   p.splitk == 1 && p.lnf_npart <= 20,
-               "LayerNorm-folding GEMM: dense, one source, K = 32 * lnf_npart <= 640, column sums + offsets, no bias, no split-K");
+                   p.splitk == 1 && p.lnf_npart <= 40,
+               "LayerNorm-folding GEMM: dense, one source, K = 32 * lnf_npart <= 1280, column sums + offsets, no bias, no split-K");
   if (p.gn_n) {
     SDMI_CHECK(p.mode == EPI_PLAIN && p.gn_n <= 2 && (p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need plain mode and Hout*Wout % 32 == 0");
     SDMI_CHECK(p.N % 4 == 0, "GroupNorm statistics: N % 4 == 0");

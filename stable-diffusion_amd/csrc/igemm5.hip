@@ -242,7 +242,6 @@ int launch_cfg5(const IGemmParams& p, int splitk, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
-  q.epi_pre = 0;
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);

@@ -114,14 +114,21 @@ __device__ __forceinline__ void slab_get(const float* wl, f32x16 (&a)[TN], int l
 
 // Row statistics of a GEMM that folds the LayerNorm of its input rows (IGemmParams::lnf_*): the producer left {sum, sum of
 // squares} per 32-column block.  lnf_request: thread i < BM asks for the partials of row m at the very top of the kernel (plain
-// loads, up to LNF_MAXP blocks = 640 channels); lnf_finish folds them (block order, fp32: deterministic) once the operand
+// loads, up to LNF_MAXP blocks = 1280 channels); lnf_finish folds them (block order, fp32: deterministic) once the operand
 // prologue has been issued -- the first version fetched and folded (fp64) between the DMA issue and the first barrier, two
 // dependent round trips + a double-precision rsqrt on every workgroup's critical path: +7 us on a 640-workgroup GEMM.
-constexpr int LNF_MAXP = 20;
+constexpr int LNF_MAXP = 40;                            // 1280 channels
 __device__ __forceinline__ void lnf_request(const IGemmParams& p, int m, float2 (&pv)[LNF_MAXP]) {
   const float2* src = (const float2*)p.lnf_part + m;
 #pragma unroll
-  for (int j = 0; j < LNF_MAXP; ++j) pv[j] = src[(size_t)min(j, p.lnf_npart - 1) * p.M];
+  for (int j = 0; j < 20; ++j) pv[j] = src[(size_t)min(j, p.lnf_npart - 1) * p.M];
+  if (p.lnf_npart > 20) {                                // (wave-uniform: the second half only for > 640 channels)
+#pragma unroll
+    for (int j = 20; j < LNF_MAXP; ++j) pv[j] = src[(size_t)min(j, p.lnf_npart - 1) * p.M];
+  } else {
+#pragma unroll
+    for (int j = 20; j < LNF_MAXP; ++j) pv[j] = float2{0.f, 0.f};
+  }
 }
 __device__ __forceinline__ void lnf_finish(const IGemmParams& p, const float2 (&pv)[LNF_MAXP], float* mean, float* rstd) {
   float s = 0.f, q = 0.f;
@@ -142,42 +149,6 @@ __device__ __forceinline__ float sum8_dpp(float v) {
   return v;
 }
 
-// Residual quads of the 16-byte epilogue requested in the kernel PROLOGUE: the short-K GEMMs on the residual stream (to_out, FF2,
-// proj_out: 5-20 k-tiles) otherwise end with a dependent load -> add -> store chain per workgroup, with every co-resident
-// workgroup in it at the same time.  Only for tiles whose lane needs <= 4 quads (64 x 64, 4 waves: 16 VGPRs through the k-loop),
-// and only when the epilogue will take its 16-byte path for this tile (same predicate as in igemm_epilogue).  In-place
-// residuals (out == residual) are fine: a workgroup reads its own tile before it writes it.
-template <int BM, int BN, int WARPS_M, int WARPS_N>
-struct EpiPre {
-  static constexpr int WTN = BN / WARPS_N, TM = BM / WARPS_M / 32;
-  static constexpr int NP = (WTN == 32 || WTN == 64) ? SLAB_NPASS<(WTN == 32 || WTN == 64) ? WTN : 32> : 0;
-  static constexpr int NQ = TM * NP;
-  static constexpr bool OK = NQ >= 1 && NQ <= 4;
-};
-template <int BM, int BN, int WARPS_M, int WARPS_N>
-__device__ __forceinline__ bool epi_prefetch_residual(const IGemmParams& p, int m0, int n0, f32x4 (&r)[4]) {
-  using E = EpiPre<BM, BN, WARPS_M, WARPS_N>;
-  if constexpr (!E::OK) { return false; }
-  else {
-    constexpr int WTM = BM / WARPS_M, WTN = E::WTN;
-    const int HWout = p.Hout * p.Wout;
-    const bool full = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    const bool one_batch = ((m0 + BM - 1) / HWout == m0 / HWout);
-    const bool want = p.mode == EPI_PLAIN && p.residual && p.epi_vec && full && one_batch && p.splitk <= 1;
-    if (!want) return false;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;
-    const int mw = m0 + wm * WTM, nw = n0 + wn * WTN;
-    const int rl = lane / SLAB_LPR<WTN>, c4 = (lane % SLAB_LPR<WTN>) * 4;
-#pragma unroll
-    for (int i = 0; i < E::TM; ++i)
-#pragma unroll
-      for (int q = 0; q < E::NP; ++q)
-        r[i * E::NP + q] = *(const f32x4*)(p.residual + (size_t)(mw + i * 32 + q * SLAB_RPI<WTN> + rl) * p.ldr + nw + c4);
-    return true;
-  }
-}
-
 // The epilogue shared by the GEMM kernels (generic implicit GEMM and the halo-staged 3x3 convolution): accumulators of the
 // wave's TM x TN MFMA tiles -> bias / time-embedding row vector / residual / fp32 + fp16 (+ split-fp16 low half) stores,
 // GEGLU, per-head q / k / v^T scatter, split-K slabs, GroupNorm statistics.  `smem` = the block's LDS (free at this point:
@@ -186,7 +157,7 @@ template <int BM, int BN, int WARPS_M, int WARPS_N, int LDS_BYTES>
 __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 (&acc)[BM / WARPS_M / 32][BN / WARPS_N / 32],
                                                const int m0, const int n0, const int split, const int tile_m,
                                                const int tile_n, unsigned char* smem, const float lnf_mean = 0.f,
-                                               const float lnf_rstd = 1.f, const f32x4* pre_res = nullptr) {
+                                               const float lnf_rstd = 1.f) {
 #ifdef SDMI_IGEMM_TIMING
   IGemmParams p = p_arg;                                  // timing build: epilogue ablations (wrong results, time only)
   if (p.dbg_abl & 1) p.residual = nullptr;
@@ -323,10 +294,7 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
         slab_put<TN, LSTR>(wl, acc[i], l31, lg);
         constexpr int NP = SLAB_NPASS<WTN>, RPI = SLAB_RPI<WTN>;
         f32x4 resv[NP];
-        if (pre_res) {                                     // fetched in the kernel prologue (epi_prefetch_residual)
-#pragma unroll
-          for (int q = 0; q < NP; ++q) resv[q] = pre_res[i * NP + q];
-        } else if (p.residual) {
+        if (p.residual) {
 #pragma unroll
           for (int q = 0; q < NP; ++q)
             resv[q] = *(const f32x4*)(p.residual + (size_t)(mw + i * 32 + q * RPI + rl) * p.ldr + nw + c4);

@@ -568,7 +568,7 @@ struct Fwd : FwdBase {
     //  * folded into the GEMM that READS it (IGemmParams::lnp_out / lnf_*): the producer stores ln = fp16(gamma * t) and the row
     //    statistics, the consumer corrects its accumulators -- no launch; taken where the producer is not split (many rows);
     //  * a post-op launch behind the producer (launch_igemm issues it after the GEMM / its split-K reduce): ln = LN(t).
-    const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 640 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
+    const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 1280 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
     float* lnp = fold_ln ? S<float>((size_t)(C / 32) * M * 2) : nullptr;
     auto with_ln = [&](IGemmParams& p, const float* gamma, const float* beta) {
       if (fold_ln) { p.out_f16 = ln; p.f16_scale = gamma; p.lnp_out = lnp; p.splitk = 1; }
@@ -609,7 +609,7 @@ struct Fwd : FwdBase {
       }
       // x = attn2(norm2(x), context) + x                           attention.py:213
       if (ctx16) context_kv(L, d);
-      if (fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx)) {
+      if (fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx) && !(fold_ln && C > 640)) {
         // to_q inside the attention kernel (attn_ctx.hip): one launch for q = norm2(x) Wq^T and softmax(q K^T) V
         AttnCtxParams a;
         a.x = ln; a.wq = T.wq2; a.k = T.ck; a.vt = T.cvt; a.out = ao;

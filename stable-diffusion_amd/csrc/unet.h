@@ -312,9 +312,9 @@ class UNet {
   hipStream_t side_ = nullptr; hipEvent_t side_ev_[32] = {};
   bool fuse_gn_stats_ = true;   // SDMI_FUSE_GN_STATS=0: every GroupNorm runs its own statistics kernel (A/B, debugging)
   // The LayerNorms of a BasicTransformerBlock (attention.py:211-215) folded into the GEMMs that read them, where the producing
-  // GEMM is not split (>= ln_fold_min_rows_ token rows): no LayerNorm launch, one fp32 read of the token stream less per site.
+  // GEMM is not split (>= ln_fold_min_rows_ token rows; the fold pins its producers to split 1): no LayerNorm launch, one fp32 read of the token stream less per site.
   // SDMI_LN_FOLD=0 restores the launches (A/B); SDMI_LN_FOLD_MIN_ROWS moves the threshold.
-  bool ln_fold_ = true; int ln_fold_min_rows_ = 2048;
+  bool ln_fold_ = true; int ln_fold_min_rows_ = 512;
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
   std::vector<Layer> middle_;
