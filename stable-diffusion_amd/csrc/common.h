@@ -174,6 +174,10 @@ struct IGemmTune {        // runtime knobs (tests sweep them; the executor takes
 };
 
 int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream);
+// split-fp16 1x1 conv with GroupNorm(32) of its fp32 input rows applied while the A operand is staged (gemm_split16.hip,
+// gemm_split16_gn_kernel): x = xf0 [M][K], statistics gn_in_acc (complete), gn_in_gamma / beta / eps, weights packed [N][3K]
+bool split16_gn_supported(const IGemmParams& p);
+int launch_split16_gn(const IGemmParams& p, hipStream_t stream);
 // may a stride-1 3x3 convolution over cat(c0, c1) fp32 channels at B x H x W fold the GroupNorm(32) of its input into its
 // staging (IGemmParams::xf0 / gn_in_*; conv3halo.hip)?
 bool gn_fold_conv_supported(int B, int H, int W, int c0, int c1, int N);

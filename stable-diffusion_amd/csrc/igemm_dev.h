@@ -673,6 +673,7 @@ bool halo_supported(const IGemmParams& p, int bm);
 int launch_halo_tile(int tile, const IGemmParams& p, int splitk, hipStream_t stream);
 // split-fp16 dense GEMM family (gemm_split16.hip): the tile ids of kTiles it instantiates
 bool split16_tile_supported(int tile);
+
 int launch_split16_tile(int tile, const IGemmParams& p, int splitk, hipStream_t stream);
 // ... with GroupNorm(32) + SiLU of the fp32 input folded into the staging (IGemmParams::xf0 / gn_in_*)
 bool halo_gn_supported(const IGemmParams& p, int bm);

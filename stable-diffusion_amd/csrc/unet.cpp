@@ -456,6 +456,10 @@ struct Fwd : FwdBase {
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
   bool fuse_ctx_q = false;
   int fuse_ctx_maxd = 160;      // ... for head dims up to this (SDMI_ATTN_CTX_MAXD)
+  // SpatialTransformer norm applied inside the proj_in GEMM (gemm_split16_gn_kernel), SDMI_GN_PROJ_FOLD=1.  Default off: bit-identical,
+  // 15 launches fewer, but 7.05 vs 6.86 ms per UNet call same box (profiles/experiments_r03.txt): -4.7 us per site at 2048 rows, a tie at
+  // 8192, +7 us at 512 rows / 1280 channels (20 k-tiles, each one drained register-load round trip)
+  bool gn_proj_fold = false;
   float* emb_all = nullptr;     // [B][emb_total] (emb_ld = emb_total), or one row of the timestep table shared by every sample (emb_ld = 0)
   int emb_ld = 0;
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
@@ -556,7 +560,15 @@ struct Fwd : FwdBase {
     const size_t mark = scratch.off;
     f16* xn = S<f16>((size_t)M * C);
     f16* xn_lo = precise_1x1 ? S<f16>((size_t)M * C) : nullptr;
-    groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
+    // proj_in(norm(x)), attention.py:254-255: the GroupNorm either as its own launch (fp32 stream -> split-fp16 hi | lo operands) or
+    // applied inside the GEMM while it stages its A operand (gemm_split16_gn_kernel: same operand bits, same products, one launch less)
+    IGemmParams pin;
+    pin.M = M; pin.N = C; pin.K = C; pin.ksize = 1; pin.Hout = N; pin.Wout = 1; pin.B = B;
+    const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 1280 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
+    const bool gn_in_gemm = gn_proj_fold && fold_ln && precise_1x1 && M >= 512 && split16_gn_supported(pin);
+    long long* gn_stats = nullptr;
+    if (gn_in_gemm) gn_stats = groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
+    else groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
     float* t = S<float>((size_t)M * C);
     f16* ln = S<f16>((size_t)M * C);
     f16* q = S<f16>((size_t)M * C);
@@ -568,7 +580,6 @@ struct Fwd : FwdBase {
     //  * folded into the GEMM that READS it (IGemmParams::lnp_out / lnf_*): the producer stores ln = fp16(gamma * t) and the row
     //    statistics, the consumer corrects its accumulators -- no launch; taken where the producer is not split (many rows);
     //  * a post-op launch behind the producer (launch_igemm issues it after the GEMM / its split-K reduce): ln = LN(t).
-    const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 1280 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
     float* lnp = fold_ln ? S<float>((size_t)(C / 32) * M * 2) : nullptr;
     auto with_ln = [&](IGemmParams& p, const float* gamma, const float* beta) {
       if (fold_ln) { p.out_f16 = ln; p.f16_scale = gamma; p.lnp_out = lnp; p.splitk = 1; }
@@ -578,7 +589,15 @@ struct Fwd : FwdBase {
       if (!fold_ln) return;
       p.lnf_part = lnp; p.lnf_npart = C / 32; p.lnf_eps = 1e-5f; p.lnf_cs = cs; p.lnf_d = dn; p.bias = nullptr;
     };
-    {
+    if (gn_in_gemm) {
+      IGemmParams p = dense(nullptr, M, C, L.w16[0], C, N);
+      p.xf0 = x.p; p.gn_in_acc = gn_stats; p.gn_in_gamma = L.f32[0]; p.gn_in_beta = L.f32[1]; p.gn_in_eps = 1e-6f; p.gn_in_silu = 0;
+      p.ldw = 3 * C; p.splitk = 1;
+      p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
+      with_ln(p, L.tb[0].ln[0], L.tb[0].ln[1]);
+      if (p.ln_out) ok(fail("internal: GroupNorm-folding proj_in needs the LayerNorm fold"));
+      if (!dry && !rc) ok(launch_split16_gn(p, s));
+    } else {
       IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N);
       p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
       with_ln(p, L.tb[0].ln[0], L.tb[0].ln[1]);                      // norm1 of the first block
@@ -812,6 +831,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);
+    const char* e_gp = getenv("SDMI_GN_PROJ_FOLD");
+    f.gn_proj_fold = (e_gp && atoi(e_gp) != 0) && f.ln_fold_on;       // (the kernel has no LayerNorm post-op launch: it rides on the fold)
   }
   if (side_stream_ && !dry && !prof_enabled()) {      // (the per-launch profiler times launches on one stream)
     if (!side_) {

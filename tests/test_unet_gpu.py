@@ -376,3 +376,21 @@ def test_refuses_cpu_and_bad_config():
     with pytest.raises(NotImplementedError):
         UNetModelHIP(image_size=32, in_channels=4, model_channels=64, out_channels=4, num_res_blocks=2,
                      attention_resolutions=[1], legacy=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('cfg_name,B,h,w', [('sdv1', 2, 32, 32), ('sdv1', 2, 64, 64)])
+def test_groupnorm_inside_proj_in_is_bit_identical(cfg_name, B, h, w, monkeypatch):
+    """SpatialTransformer: proj_in(norm(x)) (attention.py:254-255) with the GroupNorm applied inside the split-fp16 GEMM while it
+    stages its A operand (gemm_split16_gn_kernel) against the GroupNorm-apply launch + GEMM it replaces: the same operand bits
+    and the same products in the same order (the producers are unsplit on both paths) -- eps must not change by one bit."""
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, 0)
+    x, t, ctx = make_inputs(cfg, B, h, w, seed=13)
+    monkeypatch.setenv('SDMI_GN_PROJ_FOLD', '1')
+    e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_GN_PROJ_FOLD', '0')
+    e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(e1).all()
+    assert torch.equal(e0, e1), float((e0 - e1).abs().max())
