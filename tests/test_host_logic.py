@@ -415,3 +415,26 @@ def test_timestep_table_host_plumbing(monkeypatch):
     m.hint_timestep(7)
     with pytest.raises(RuntimeError, match='hint_timestep'):
         m.forward(x[:2], torch.full((2,), 5, dtype=torch.long), context=ctx[:2])
+
+
+def test_design_knob_table_matches_the_sources():
+    """Every SDMI_* environment knob that DESIGN.md's table documents is read somewhere in the sources, and every knob the library /
+    host package reads is documented (or a profiles / tools file for the bisecting-only ones) -- the table cannot rot."""
+    import re
+    design = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    table = design[design.index('### Environment knobs'):design.index('### What the measurements say (MI355X, round 1)')]
+    documented = set(re.findall(r'SDMI_[A-Z0-9_]+', table))
+    read = set()
+    for base, exts in ((os.path.join(ROOT, 'stable-diffusion_amd', 'csrc'), ('.hip', '.cpp', '.h')),
+                       (os.path.join(ROOT, 'stable-diffusion_amd'), ('.py',)), (ROOT, ('bench.py',))):
+        for fn in sorted(os.listdir(base)):
+            if fn.endswith(exts):
+                src = open(os.path.join(base, fn)).read()
+                read |= set(re.findall(r'(?:getenv|env_int|environ\.get|environ\[)\(?\s*[\'"](SDMI_[A-Z0-9_]+)', src))
+    # build-time / test-only names that are not run-time knobs of the library
+    not_knobs = {'SDMI_CXXFLAGS', 'SDMI_LIB_OUT', 'SDMI_REGEN_GOLDEN', 'SDMI_IGEMM_TIMING', 'SDMI_EPI_ABL', 'SDMI_ATTN_NW', 'SDMI_ATTN_ABL',
+                 'SDMI_NT_STORES', 'SDMI_GN_VISIBLE', 'SDMI_GN_XBAR', 'SDMI_GN_POISON', 'SDMI_LIB_PATH'}
+    missing_in_code = sorted(k for k in documented - read - not_knobs)
+    assert not missing_in_code, f'documented in DESIGN.md but read nowhere: {missing_in_code}'
+    undocumented = sorted(k for k in read - documented - not_knobs)
+    assert not undocumented, f'read by the sources but missing from the DESIGN.md knob table: {undocumented}'
