@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 10
+#define SDMI_ABI_VERSION 11
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -231,6 +231,13 @@ typedef struct sdmi_igemm_desc {
    * rstd_m * (acc - mean_m * lnf_cs[n]) + lnf_d[n] (vectors from sdmi_k_ln_fold_prep) before the mode's epilogue. */
   const float* f16_scale; float* lnp_out;
   const float* lnf_part; int32_t lnf_npart; float lnf_eps; const float* lnf_cs; const float* lnf_d;
+  /* GroupNorm(32, pgn_eps) (+ SiLU) of the finished OUTPUT inside the split-K reduction (ABI 11; mode 0, N % 128 == 0, Hout*Wout *
+   * N / 128 <= 5120: ResBlock conv1 -> out_layers.0-1, openaimodel.py:225-227): when the GEMM is split, one workgroup per (sample,
+   * group) sums the slabs, takes the group's statistics and stores pgn_out [M][N] fp16 = SiLU(GN(v)); out_f32 is then written
+   * only with pgn_keep_f32.  *pgn_applied (host int, optional) is set to 1 when that happened; when it is left 0 the launch was an
+   * ordinary one and pgn_out is untouched. */
+  const float* pgn_gamma; const float* pgn_beta; float pgn_eps; int32_t pgn_silu;
+  void* pgn_out; int32_t pgn_keep_f32; int32_t* pgn_applied;
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
 /* cs[n] = sum_k gamma[k] * w[n][k], d[n] = sum_k beta[k] * w[n][k] (+ bias[n]) over the PACKED fp16 weights w [N][ldw]

@@ -44,7 +44,9 @@ class IGemmDesc(C.Structure):
                 ('gn_n', C.c_int32), ('gn_acc', c_ptr * 2), ('gn_cpg', C.c_int32 * 2), ('gn_cbase', C.c_int32 * 2),
                 ('splitk_cnt', c_ptr), ('splitk_cnt_ints', C.c_int32), ('split16', C.c_int32),
                 ('f16_scale', c_ptr), ('lnp_out', c_ptr), ('lnf_part', c_ptr), ('lnf_npart', C.c_int32),
-                ('lnf_eps', C.c_float), ('lnf_cs', c_ptr), ('lnf_d', c_ptr)]
+                ('lnf_eps', C.c_float), ('lnf_cs', c_ptr), ('lnf_d', c_ptr),
+                ('pgn_gamma', c_ptr), ('pgn_beta', c_ptr), ('pgn_eps', C.c_float), ('pgn_silu', C.c_int32),
+                ('pgn_out', c_ptr), ('pgn_keep_f32', C.c_int32), ('pgn_applied', C.POINTER(C.c_int32))]
 
 
 _SIGS = {
@@ -147,7 +149,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 10:
+        if lib.sdmi_abi_version() != 11:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

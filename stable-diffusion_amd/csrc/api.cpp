@@ -258,6 +258,8 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   }
   p.f16_scale = d->f16_scale; p.lnp_out = d->lnp_out;
   p.lnf_part = d->lnf_part; p.lnf_npart = d->lnf_npart; p.lnf_eps = d->lnf_eps; p.lnf_cs = d->lnf_cs; p.lnf_d = d->lnf_d;
+  p.pgn_gamma = d->pgn_gamma; p.pgn_beta = d->pgn_beta; p.pgn_eps = d->pgn_eps; p.pgn_silu = d->pgn_silu;
+  p.pgn_out = (f16*)d->pgn_out; p.pgn_keep_f32 = d->pgn_keep_f32; p.pgn_applied = d->pgn_applied;
   if (zero_page(&p.zero_page)) return -1;
   IGemmTune t; t.tile = d->tile; t.dma = d->dma;
   return launch_igemm(p, t, (hipStream_t)stream);

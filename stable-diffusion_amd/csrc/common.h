@@ -31,6 +31,24 @@ __device__ __forceinline__ void gn_acc_add(unsigned long long* dst, float v) {
 __device__ __forceinline__ double gn_acc_value(long long hi, long long lo) {
   return (double)hi + (double)lo * (1.0 / 1099511627776.0);
 }
+// the two words gn_acc_add adds for one fp32 partial (same expressions: a kernel that sums its partials in registers instead of
+// through the accumulator words arrives at the same integers)
+__device__ __forceinline__ void gn_fixed_split(float v, long long* hi, long long* lo) {
+  const double d = (double)v;
+  const double h = rint(d);
+  *hi = (long long)h;
+  *lo = __double2ll_rn((d - h) * 1099511627776.0);
+}
+// {mean, rstd} of a group from its folded totals {sum, sum of squares} (integer + 2^-40 fraction words), n elements: ONE expression
+// for every kernel that normalises (norm.hip's apply kernel, the split-K reduction that applies a GroupNorm) -- same bits
+__device__ __forceinline__ void gn_mean_rstd(long long s, long long sl, long long ss, long long ssl, double n, float eps,
+                                             float* mean, float* rstd) {
+  const double m = gn_acc_value(s, sl) / n;
+  double var = gn_acc_value(ss, ssl) / n - m * m;
+  if (var < 0.0) var = 0.0;
+  *mean = (float)m;
+  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+}
 #endif
 
 namespace sdmi {
@@ -70,6 +88,32 @@ enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 #define SDMI_ST(T, ptr, val) __builtin_nontemporal_store((T)(val), (T*)(ptr))
 #else
 #define SDMI_ST(T, ptr, val) (*(T*)(ptr) = (T)(val))
+#endif
+// -DSDMI_WT_STORES=1|2 (round-4 experiment, same question): the 16-byte fp32 output stores (=2: the 8-byte fp16 ones as well)
+// carry the sc1 bit, i.e. they are written THROUGH the XCD's L2 while the kernel runs instead of sitting dirty in it until the
+// end-of-kernel write-back (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s; `nt` is not write-through, sc1 is; a
+// 16-byte sc1 store costs what a plain one does, narrower ones are one fabric write each).  base = wave-uniform tensor base,
+// off = element offset (byte offset < 2^31: checked by the launchers' workspace sizes).
+#if defined(__HIPCC__) && defined(SDMI_WT_STORES)
+typedef unsigned sdmi_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sdmi_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void sdmi_st_wt16(const void* base, size_t byte_off, f32x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sdmi_u32x4, v), r, (int)byte_off, 0, 16);
+}
+__device__ __forceinline__ void sdmi_st_wt8(const void* base, size_t byte_off, f16x4 v) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sdmi_u32x2, v), r, (int)byte_off, 0, 16);
+}
+#define SDMI_ST_F32X4(base, off, val) sdmi_st_wt16((base), (size_t)(off) * 4, (val))
+#if SDMI_WT_STORES >= 2
+#define SDMI_ST_F16X4(base, off, val) sdmi_st_wt8((base), (size_t)(off) * 2, (val))
+#else
+#define SDMI_ST_F16X4(base, off, val) SDMI_ST(f16x4, (base) + (off), (val))
+#endif
+#else
+#define SDMI_ST_F32X4(base, off, val) SDMI_ST(f32x4, (base) + (off), (val))
+#define SDMI_ST_F16X4(base, off, val) SDMI_ST(f16x4, (base) + (off), (val))
 #endif
 
 struct IGemmParams {
@@ -145,6 +189,16 @@ struct IGemmParams {
   long long* gn_acc[2] = {nullptr, nullptr};
   int gn_cpg[2] = {0, 0}, gn_cbase[2] = {0, 0};
   unsigned long long gn_magic[2] = {0, 0};             // ceil(2^40 / gn_cpg), filled by the launcher
+  // optional (plain mode, round 4): GroupNorm(32) (+ SiLU) of the finished OUTPUT applied by the split-K reduction itself --
+  // ResBlock conv1 -> out_layers' GroupNorm + SiLU -> conv2 (openaimodel.py:225-231).  When this GEMM ends up split and the
+  // geometry fits (splitk_reduce_gn_kernel: one workgroup per (sample, group) sums the slabs, has the whole group in registers,
+  // takes its statistics there and stores pgn_out = fp16(SiLU(GN(v))) -- the conv2 operand; no statistics atomics, no
+  // GroupNorm-apply launch, and the fp32 value v is not stored unless pgn_keep_f32), *pgn_applied is set to 1; otherwise it is
+  // left alone and the caller runs its GroupNorm-apply launch as before.
+  const float* pgn_gamma = nullptr; const float* pgn_beta = nullptr; float pgn_eps = 1e-5f; int pgn_silu = 1;
+  f16* pgn_out = nullptr;                              // [M][N] fp16
+  int pgn_keep_f32 = 0;                                // also store out_f32 (someone besides that GroupNorm reads it)
+  int* pgn_applied = nullptr;                          // host flag, written by the launcher
   // filled by the launcher: ceil(2^40 / (Hout*Wout)) and ceil(2^40 / Wout) for the kernel's division-free row split
   unsigned long long magic_hw = 0, magic_w = 0, magic_w2 = 0;   // (magic_w2: Wout + 2, halo-staged conv)
   int log2w = 0;

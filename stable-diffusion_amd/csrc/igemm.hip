@@ -403,8 +403,8 @@ __global__ void __launch_bounds__(256) splitk_reduce_kernel(IGemmParams p, int n
     v += biasv;
     if (p.rowvec) v += rvv;
     if (p.residual) v += resv;
-    if (p.out_f32) SDMI_ST(f32x4, p.out_f32 + (size_t)m * p.ldo + n, v);
-    if (p.out_f16) SDMI_ST(f16x4, p.out_f16 + (size_t)m * p.ldo + n, (f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}));
+    if (p.out_f32) SDMI_ST_F32X4(p.out_f32, (size_t)m * p.ldo + n, v);
+    if (p.out_f16) SDMI_ST_F16X4(p.out_f16, (size_t)m * p.ldo + n, (f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}));
     if (p.out_lo) {
       f16x4 lo;
 #pragma unroll
@@ -473,6 +473,121 @@ __global__ void __launch_bounds__(256) splitk_reduce_heads_kernel(IGemmParams p,
   }
 }
 
+// Split-K reduction + GroupNorm(32) (+ SiLU) of the result in ONE launch (IGemmParams::pgn_*; ResBlock conv1 -> out_layers'
+// GroupNorm -> SiLU, openaimodel.py:225-231, at the levels where conv1 is split: 8x8, 16x16, the concat blocks of 32x32).
+// Workgroup (g, b) owns group g of sample b: HW rows x cpg = N / 32 channels.  Thread t handles the 16-byte quads t, t + 1024, ...
+// of that block (quad = 4 channels of a row): it sums their nsplit partials in slab order, + bias + rowvec + residual -- the
+// operations of splitk_reduce_kernel in the same order, i.e. the same fp32 value v -- and keeps v in registers.
+// Statistics, BIT-IDENTICAL to the path it replaces (splitk_reduce_kernel's statistics + norm.hip's fold): there, with 32 rows per
+// block (every shape this kernel accepts: the launcher checks), a thread's partial is ONE quad's {((v0 + v1) + v2) + v3, the same
+// over the rounded squares}, added as fixed-point int64 words -- exact, order-free -- and folded by gn_mean_rstd.  Here the same
+// per-quad fp32 partials are split into the same words (gn_fixed_split), summed as integers in registers / LDS, and folded by
+// the same function; every thread then normalises its quads with gn_apply_elem (the apply kernel's arithmetic) into pgn_out, the
+// fp16 operand of conv2.  No statistics atomics, no GroupNorm-apply launch, and v is not written at all unless pgn_keep_f32.
+__device__ __forceinline__ void quad_partials(const f32x4 a, float* q1, float* q2) {
+#pragma clang fp contract(off)
+  // (no fused multiply-add: splitk_reduce_kernel adds the rounded squares -- its product feeds two exec-masked branches)
+  *q1 = ((a[0] + a[1]) + a[2]) + a[3];
+  const float s0 = a[0] * a[0], s1 = a[1] * a[1], s2 = a[2] * a[2], s3 = a[3] * a[3];
+  *q2 = ((s0 + s1) + s2) + s3;
+}
+template <int MAXQ>
+__global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(IGemmParams p, int nsplit, unsigned long long magic_qpr) {
+  __shared__ long long s_red[16][4];
+  const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const int HW = p.Hout * p.Wout;
+  const int cpg = p.N >> 5, qpr = cpg >> 2;
+  const int total = HW * qpr;
+  const size_t slab_sz = (size_t)p.M * p.N;
+  f32x4 v[MAXQ];
+  long long w[4] = {0, 0, 0, 0};                       // {sum int, sum frac, sumsq int, sumsq frac} of this thread's quads
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int idx = tid + i * 1024;
+    v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (idx < total) {
+      const int row = fast_div(idx, magic_qpr);
+      const int n = g * cpg + (idx - row * qpr) * 4;
+      const size_t m = (size_t)b * HW + row;
+      const float* src = p.splitk_ws + m * p.N + n;
+      f32x4 biasv = {0.f, 0.f, 0.f, 0.f}, rvv = {0.f, 0.f, 0.f, 0.f}, resv = {0.f, 0.f, 0.f, 0.f};
+      if (p.bias) biasv = *(const f32x4*)(p.bias + n);
+      if (p.rowvec) rvv = *(const f32x4*)(p.rowvec + (size_t)b * p.ld_rowvec + n);
+      if (p.residual) resv = *(const f32x4*)(p.residual + m * p.ldr + n);
+      f32x4 part[16];
+#pragma unroll
+      for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * slab_sz) : f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 a = part[0];
+#pragma unroll
+      for (int s = 1; s < 16; ++s) a += part[s];       // fixed order; absent splits add +0
+      a += biasv;
+      if (p.rowvec) a += rvv;
+      if (p.residual) a += resv;
+      v[i] = a;
+      if (p.out_f32 && p.pgn_keep_f32) SDMI_ST_F32X4(p.out_f32, m * p.ldo + n, a);
+      // the quad's partials as splitk_reduce_kernel forms them: plain adds over the values, plain adds over the ROUNDED squares
+      float q1, q2;
+      quad_partials(a, &q1, &q2);
+      long long hi, lo;
+      gn_fixed_split(q1, &hi, &lo); w[0] += hi; w[1] += lo;
+      gn_fixed_split(q2, &hi, &lo); w[2] += hi; w[3] += lo;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) w[k] += __shfl_xor(w[k], o);      // integer adds: exact in any order
+  }
+  if ((tid & 63) == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) s_red[tid >> 6][k] = w[k];
+  }
+  __syncthreads();
+  long long t[4] = {0, 0, 0, 0};
+#pragma unroll
+  for (int wv = 0; wv < 16; ++wv)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) t[k] += s_red[wv][k];
+  float mean, rstd;
+  gn_mean_rstd(t[0], t[1], t[2], t[3], (double)cpg * (double)HW, p.pgn_eps, &mean, &rstd);
+#pragma unroll
+  for (int i = 0; i < MAXQ; ++i) {
+    const int idx = tid + i * 1024;
+    if (idx < total) {
+      const int row = fast_div(idx, magic_qpr);
+      const int n = g * cpg + (idx - row * qpr) * 4;
+      const size_t m = (size_t)b * HW + row;
+      const f32x4 ga = *(const f32x4*)(p.pgn_gamma + n), be = *(const f32x4*)(p.pgn_beta + n);
+      f16x4 y;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = (f16)gn_apply_elem(v[i][j], mean, rstd, ga[j], be[j], p.pgn_silu);
+      SDMI_ST_F16X4(p.pgn_out, m * p.N + n, y);
+    }
+  }
+}
+
+// rows per block of splitk_reduce_kernel: 32 (one row per thread) up to 256, doubling while the grid keeps >= 1024 blocks
+static int reduce_rows_per_block(const IGemmParams& p) {
+  int rpb = 32;
+  const int hw = p.Hout * p.Wout;
+  while (rpb < 256 && (int64_t)cdiv(p.N / 4, 8) * cdiv(p.M, rpb * 2) >= 1024 && (p.gn_n == 0 || hw % (rpb * 2) == 0)) rpb *= 2;
+  return rpb;
+}
+
+// may the reduction of this split GEMM apply the consuming GroupNorm itself (IGemmParams::pgn_*)?  SDMI_REDUCE_GN=0: never (A/B)
+static int reduce_gn_maxq(const IGemmParams& p, int nsplit) {
+  const int on = env_int("SDMI_REDUCE_GN", 1);      // (read per launch: the tests flip it between two forwards)
+  const int hw = p.Hout * p.Wout;
+  if (!on || !p.pgn_out || !p.pgn_gamma || !p.pgn_beta || p.mode != EPI_PLAIN || nsplit < 2 || nsplit > 16) return 0;
+  if (p.N % 128 || p.M != p.B * hw || p.out_f16 || p.out_lo || p.ln_out || p.lnp_out || p.gn_n > 1) return 0;
+  if (p.gn_n == 1 && (p.gn_cbase[0] != 0 || p.gn_cpg[0] != p.N / 32)) return 0;      // statistics wanted by some OTHER GroupNorm
+  if (p.pgn_keep_f32 && (!p.out_f32 || p.ldo % 4)) return 0;
+  if (p.ldr % 4 || p.ld_rowvec % 4) return 0;
+  if (reduce_rows_per_block(p) != 32) return 0;         // (the statistics are then the two-launch path's, bit for bit: see the kernel)
+  const int64_t quads = (int64_t)hw * (p.N / 128);
+  return quads <= 1024 ? 1 : quads <= 3 * 1024 ? 3 : quads <= 5 * 1024 ? 5 : 0;
+}
+
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int tiles_m = cdiv(p.M, BM), tiles_n = cdiv(p.N, BN);
@@ -529,6 +644,20 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
 
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   SDMI_CHECK(nsplit >= 1 && nsplit <= 16 && p.N % 4 == 0 && p.splitk_ws, "splitk_reduce: bad arguments");
+  if (const int maxq = reduce_gn_maxq(p, nsplit)) {       // the consuming GroupNorm (+ SiLU) inside the reduction: see the kernel
+    const unsigned long long magic_qpr = div_magic(p.N / 128);
+    const double mn = (double)p.M * p.N;
+    ProfScope psg("splitk_reduce_gn", 0.0, mn * 4.0 * nsplit + mn * 2.0 + (p.residual ? mn * 4.0 : 0.0) + (p.pgn_keep_f32 ? mn * 4.0 : 0.0), stream);
+    const dim3 grid(32, (unsigned)p.B), block(1024);
+    if (maxq == 1) hipLaunchKernelGGL(splitk_reduce_gn_kernel<1>, grid, block, 0, stream, p, nsplit, magic_qpr);
+    else if (maxq == 3) hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, grid, block, 0, stream, p, nsplit, magic_qpr);
+    else hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, grid, block, 0, stream, p, nsplit, magic_qpr);
+    SDMI_HIP_OK(hipGetLastError());
+    psg.end();
+    if (p.pgn_applied) *p.pgn_applied = 1;
+    if (range_check_enabled() && range_scan("GroupNorm fp16 output (split-K reduction)", p.pgn_out, (int64_t)p.M * p.N, stream)) return -1;
+    return 0;
+  }
   if (p.mode == EPI_HEADS) {
     const int64_t total_h = (int64_t)p.M * (p.N / 4);
     ProfScope psh("splitk_reduce", 0.0, (double)p.M * p.N * (4.0 * nsplit + 2.0), stream);
@@ -539,10 +668,9 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   // rows per block: 32 (one row per thread) up to 256, doubling while the grid keeps >= 1024 blocks (the kernel is a
   // latency-bound stream of nsplit 16-byte loads per thread: it wants every CU busy); with GroupNorm statistics it must
   // also divide the sample's row count, so a strip never straddles two samples
-  int rpb = 32;
   const int hw = p.Hout * p.Wout;
   if (p.gn_n > 0) SDMI_CHECK(hw % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
-  while (rpb < 256 && (int64_t)cdiv(p.N / 4, 8) * cdiv(p.M, rpb * 2) >= 1024 && (p.gn_n == 0 || hw % (rpb * 2) == 0)) rpb *= 2;
+  const int rpb = reduce_rows_per_block(p);
   ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(p.N / 4, 8), (unsigned)cdiv(p.M, rpb)), dim3(256), 0, stream, p, nsplit,
                      rpb);

@@ -308,10 +308,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
           float* const lp = wl + row * LSTR + c4;
           const f32x4 v = *(const f32x4*)lp + colv + resv[q];
           const size_t ro = (size_t)(mw + i * 32 + row) * p.ldo + nw + c4;
-          if (p.out_f32) SDMI_ST(f32x4, p.out_f32 + ro, v);
+          if (p.out_f32) SDMI_ST_F32X4(p.out_f32, ro, v);
           const f32x4 vs = v * g4;                         // (g4 = 1 without a scale: exact)
           const f16x4 h = {(f16)vs[0], (f16)vs[1], (f16)vs[2], (f16)vs[3]};
-          if (p.out_f16) SDMI_ST(f16x4, p.out_f16 + ro, h);
+          if (p.out_f16) SDMI_ST_F16X4(p.out_f16, ro, h);
           if (p.out_lo)
             *(f16x4*)(p.out_lo + ro) = f16x4{(f16)(v[0] - (float)h[0]), (f16)(v[1] - (float)h[1]), (f16)(v[2] - (float)h[2]),
                                             (f16)(v[3] - (float)h[3])};

@@ -95,11 +95,7 @@ __device__ __forceinline__ void gn_fold(const long long* acc, int b, int g, int 
   for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {
     s += __shfl_xor(s, o); sl += __shfl_xor(sl, o); ss += __shfl_xor(ss, o); ssl += __shfl_xor(ssl, o);
   }
-  const double m = gn_acc_value(s, sl) / n;
-  double var = gn_acc_value(ss, ssl) / n - m * m;
-  if (var < 0.0) var = 0.0;
-  *mean = (float)m;
-  *rstd = (float)(1.0 / sqrt(var + (double)eps));
+  gn_mean_rstd(s, sl, ss, ssl, n, eps, mean, rstd);
 }
 
 // floor(m / d) for 0 <= m, m * d < 2^40, magic = ceil(2^40 / d) (host computed; same scheme as igemm.hip's fast_div)
@@ -158,9 +154,9 @@ __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const 
       y[j] = gn_apply_elem(v[u][j], second ? m1 : m0, second ? r1 : r0, ga[u][j], be[u][j], p.silu);
     }
     const size_t o = pix[u] * C + c;
-    if (p.out_f16) SDMI_ST(f16x4, p.out_f16 + o, (f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]}));
-    if (p.out_lo) SDMI_ST(f16x4, p.out_lo + o, lo_half(y));
-    if (p.out_f32) SDMI_ST(f32x4, p.out_f32 + o, y);
+    if (p.out_f16) SDMI_ST_F16X4(p.out_f16, o, (f16x4{(f16)y[0], (f16)y[1], (f16)y[2], (f16)y[3]}));
+    if (p.out_lo) SDMI_ST_F16X4(p.out_lo, o, lo_half(y));
+    if (p.out_f32) SDMI_ST_F32X4(p.out_f32, o, y);
     if (p.raw_f16) *(f16x4*)(p.raw_f16 + o) = f16x4{(f16)v[u][0], (f16)v[u][1], (f16)v[u][2], (f16)v[u][3]};
     if (p.raw_lo) *(f16x4*)(p.raw_lo + o) = lo_half(v[u]);
   }

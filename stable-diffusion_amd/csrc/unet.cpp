@@ -498,6 +498,7 @@ struct Fwd : FwdBase {
     float* h = S<float>((size_t)M * Cout);
     Act out = make_act(P<float>((size_t)M * Cout), Cout, H, W, true);
     Act hact = make_act(h, Cout, H, W, true);
+    f16* a2 = nullptr; int gn2_applied = 0;
     {
       IGemmParams p;
       if (fold1) {
@@ -511,6 +512,12 @@ struct Fwd : FwdBase {
       p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = emb_ld;
       p.out_f32 = h; p.ldo = Cout;
       attach_gn_targets(p, hact);          // statistics of out_layers' GroupNorm come out of this epilogue
+      if (!fold2) {
+        // ... or, where this conv ends up split along K (8x8, 16x16, the concat blocks of 32x32), GroupNorm + SiLU are applied by
+        // its split-K reduction: a2 = the conv2 operand comes straight out of it (IGemmParams::pgn_*; gn2_applied says so)
+        a2 = S<f16>((size_t)M * Cout);
+        p.pgn_gamma = L.f32[3]; p.pgn_beta = L.f32[4]; p.pgn_eps = 1e-5f; p.pgn_silu = 1; p.pgn_out = a2; p.pgn_applied = &gn2_applied;
+      }
       gemm(p);
     }
     const float* residual = x0.p;
@@ -525,8 +532,7 @@ struct Fwd : FwdBase {
       if (fold2) {
         p = conv3_gn(hact, nullptr, L.f32[3], L.f32[4], L.w16[1], Cout, nullptr, nullptr);
       } else {
-        f16* a2 = S<f16>((size_t)M * Cout);
-        groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr);
+        groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr, nullptr, nullptr, false, gn2_applied != 0);
         p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
       }
       if (Cin != Cout && !fold1) join_side();

@@ -191,8 +191,11 @@ struct FwdBase {
   // stats_only: fill (or, when the producers' epilogues did, just locate) the statistics accumulators of this GroupNorm and
   // launch no apply kernel -- the consuming convolution normalises while it stages its input (IGemmParams::gn_in_acc).
   // Returns the accumulator region.
+  // already_applied: the producing GEMM's split-K reduction normalised its output itself (IGemmParams::pgn_*): this call only
+  // keeps the plan's bookkeeping (accumulator region, call index) in step and launches nothing.
   long long* groupnorm(const Act& x0, const Act* x1, const float* gamma, const float* beta, float eps, int silu, f16* o16,
-                       float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr, bool stats_only = false) {
+                       float* o32, f16* raw, f16* o16_lo = nullptr, f16* raw_lo = nullptr, bool stats_only = false,
+                       bool already_applied = false) {
     GroupNormParams g;
     g.x0 = x0.p; g.c0 = x0.C;
     if (x1) { g.x1 = x1->p; g.c1 = x1->C; }
@@ -216,7 +219,7 @@ struct FwdBase {
         g.skip_stats = (idx < (int)plan->fused.size() && plan->fused[idx]) ? 1 : 0;
       }
     }
-    if (!dry && !rc && !(stats_only && g.skip_stats)) ok(launch_groupnorm(g, s));
+    if (!dry && !rc && !(stats_only && g.skip_stats) && !already_applied) ok(launch_groupnorm(g, s));
     return g.acc;
   }
 };

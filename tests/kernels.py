@@ -43,7 +43,7 @@ def cast_f16(x, want_lo=False):
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
           residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None, fused_splitk=True,
-          asym_pad=0, gn=None, split16=False, f16_scale=None, lnp_out=None, lnf=None):
+          asym_pad=0, gn=None, split16=False, f16_scale=None, lnp_out=None, lnf=None, pgn=None):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K].
     LayerNorm fold: producer f16_scale (gamma [N]) + lnp_out ([N/32, M, 2] fp32); consumer lnf = (partials, eps, cs, d)."""
     d = _lib.IGemmDesc()
@@ -78,6 +78,11 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
         d.gn_n = len(gn)
         for i, (acc, cpg, cbase) in enumerate(gn):
             d.gn_acc[i] = acc.data_ptr(); d.gn_cpg[i] = cpg; d.gn_cbase[i] = cbase
+    applied = C.c_int32(0)
+    if pgn is not None:    # (gamma, beta, eps, silu, out fp16 [M, N], keep_f32): GroupNorm (+ SiLU) inside the split-K reduction
+        ga, be, eps, silu, o16, keep = pgn
+        d.pgn_gamma = ga.data_ptr(); d.pgn_beta = be.data_ptr(); d.pgn_eps = float(eps); d.pgn_silu = int(silu)
+        d.pgn_out = o16.data_ptr(); d.pgn_keep_f32 = int(keep); d.pgn_applied = C.pointer(applied)
     ws = None
     if splitk != 1:
         M = B * Hout * Wout
@@ -87,6 +92,7 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
             cnt = _splitk_counters(a0.device)
             d.splitk_cnt = cnt.data_ptr(); d.splitk_cnt_ints = cnt.numel()
     _lib.check(_lib.load().sdmi_k_igemm(C.byref(d), _s()))
+    return int(applied.value)
 
 
 _CNT = {}

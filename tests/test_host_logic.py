@@ -20,7 +20,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 10
+    assert lib.sdmi_abi_version() == 11
     for name in declared:
         assert hasattr(lib, name)
 
@@ -36,7 +36,8 @@ def test_ctypes_struct_layout_matches_header():
 int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg), offsetof(sdmi_unet_cfg, context_dim),
  sizeof(sdmi_igemm_desc), offsetof(sdmi_igemm_desc, w), offsetof(sdmi_igemm_desc, seg_dst), offsetof(sdmi_igemm_desc, dma),
  offsetof(sdmi_igemm_desc, asym_pad), sizeof(sdmi_vae_cfg), offsetof(sdmi_vae_cfg, embed_dim));
- printf("%zu %zu\n", sizeof(sdmi_clip_cfg), offsetof(sdmi_clip_cfg, max_positions)); }
+ printf("%zu %zu %zu %zu\n", sizeof(sdmi_clip_cfg), offsetof(sdmi_clip_cfg, max_positions), offsetof(sdmi_igemm_desc, pgn_out),
+        offsetof(sdmi_igemm_desc, pgn_applied)); }
 '''
     d = os.path.join(ROOT, 'stable-diffusion_amd', 'build')
     os.makedirs(d, exist_ok=True)
@@ -47,7 +48,8 @@ int main(){ printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\n", sizeof(sdmi_unet_cfg
     got = [int(v) for v in subprocess.run([exe], capture_output=True, text=True, check=True).stdout.split()]
     want = [C.sizeof(_lib.UNetCfg), _lib.UNetCfg.context_dim.offset, C.sizeof(_lib.IGemmDesc), _lib.IGemmDesc.w.offset,
             _lib.IGemmDesc.seg_dst.offset, _lib.IGemmDesc.dma.offset, _lib.IGemmDesc.asym_pad.offset,
-            C.sizeof(_lib.VaeCfg), _lib.VaeCfg.embed_dim.offset, C.sizeof(_lib.ClipCfg), _lib.ClipCfg.max_positions.offset]
+            C.sizeof(_lib.VaeCfg), _lib.VaeCfg.embed_dim.offset, C.sizeof(_lib.ClipCfg), _lib.ClipCfg.max_positions.offset,
+            _lib.IGemmDesc.pgn_out.offset, _lib.IGemmDesc.pgn_applied.offset]
     assert got == want
 
 

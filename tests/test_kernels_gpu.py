@@ -243,6 +243,72 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
     assert (other - outs[0]).abs().max().item() <= 4e-6 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize('B,H,W,C,N,splitk,tile,ksize,resid', [
+    (2, 8, 8, 1280, 1280, 12, 19, 3, False),      # the 8x8 level: igemm 64x128, 12-way split (ResBlock conv1)
+    (2, 16, 16, 1280, 1280, 10, 15, 3, False),    # 16x16: halo tile, split at 64-channel chunks
+    (2, 32, 32, 1280, 640, 5, 15, 3, False),      # 32x32 concat block: 20 channels per group, 5 quads per thread
+    (2, 16, 16, 640, 1280, 5, 14, 3, True),       # with a residual
+    (3, 8, 8, 256, 128, 2, 2, 1, False),          # smallest legal width: 4 channels per group
+    (2, 16, 16, 320, 256, 0, -1, 3, False),       # auto split / auto tile: applied or not, the launcher says which
+])
+def test_igemm_splitk_reduce_applies_groupnorm(B, H, W, C, N, splitk, tile, ksize, resid):
+    """GroupNorm(32) + SiLU of a split-K conv's output applied by its reduction (splitk_reduce_gn_kernel, sdmi_igemm_desc::pgn_*):
+    against torch's GroupNorm + SiLU of the fp32 conv result, four bit-identical repeats, and against this library's own
+    GroupNorm kernels on the reduction's fp32 output (statistics kernel + apply: same elementwise function, statistics from a
+    different partition of the same values -- rounding flips only; the bit-identity with the producers' fused statistics is
+    checked on whole UNet calls, tests/test_unet_gpu.py)."""
+    g = _g(91)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, ksize, ksize), g, 1.0 / math.sqrt(ksize * ksize * C))
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    res = torch.randn(B * H * W, N, generator=g) if resid else None
+    gamma = 1.0 + 0.3 * torch.randn(N, generator=g)
+    beta = 0.2 * torch.randn(N, generator=g)
+    v_ref = _nhwc(_conv_ref(a, None, w, B, H, W, ksize, 1, 0)) + bias[None] + rowvec.repeat_interleave(H * W, dim=0)
+    if resid:
+        v_ref = v_ref + res
+    y_ref = F.silu(F.group_norm(v_ref.view(B, H * W, N).permute(0, 2, 1).double(), 32, gamma.double(), beta.double(), 1e-5))
+    y_ref = y_ref.permute(0, 2, 1).reshape(B * H * W, N).float()
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    a_d, bias_d, rv_d = a.to(DEV), bias.to(DEV), rowvec.to(DEV)
+    res_d = res.to(DEV) if resid else None
+    ga_d, be_d = gamma.to(DEV), beta.to(DEV)
+    outs = []
+    for rep in range(4):
+        o16 = torch.full((B * H * W, N), float('nan'), dtype=torch.float16, device=DEV)
+        o32 = torch.full((B * H * W, N), float('nan'), device=DEV)
+        applied = K.igemm(a_d, wp, N, B, H, W, H, W, ksize, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=o32,
+                          splitk=splitk, tile=tile, fused_splitk=False, pgn=(ga_d, be_d, 1e-5, 1, o16, rep % 2))
+        outs.append((applied, o16, o32))
+    torch.cuda.synchronize()
+    applied = outs[0][0]
+    if splitk > 1:
+        assert applied == 1
+    # the library's two launches on the same inputs: the reduce kernel's fp32 output, then GroupNorm-apply
+    v2 = torch.full((B * H * W, N), float('nan'), device=DEV)
+    K.igemm(a_d, wp, N, B, H, W, H, W, ksize, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=v2, splitk=splitk, tile=tile,
+            fused_splitk=False)
+    y2 = K.groupnorm(v2.view(B, H * W, N), None, ga_d, be_d, 1e-5, 1)['f16'].view(B * H * W, N)
+    torch.cuda.synchronize()
+    if not applied:        # the auto choice did not split: nothing was applied, the fp32 output is the ordinary one
+        assert torch.equal(outs[0][2], v2) and torch.isnan(outs[0][1].float()).all()
+        return
+    y = outs[0][1].float().cpu()
+    err = (y - y_ref).abs().max().item()
+    print(f'[reduce+gn M{B * H * W} N{N} split{splitk} tile{tile}] max-abs vs torch {err:.3e} (|y| max {y_ref.abs().max():.2f})', flush=True)
+    assert err <= 2e-3 * max(1.0, y_ref.abs().max().item())          # one fp16 rounding of values up to ~4
+    diff = (outs[0][1].float() - y2.float()).abs()
+    nflip = int((diff > 0).sum().item())
+    assert diff.max().item() <= 8e-3 and nflip <= 2e-3 * diff.numel() + 2, (diff.max().item(), nflip)    # rounding flips only
+    for rep, (ap, o16, o32) in enumerate(outs):
+        assert ap == 1 and torch.equal(o16, outs[0][1])
+        if rep % 2:
+            assert torch.equal(o32, v2)                 # pgn_keep_f32: the reduction's fp32 value, bit for bit
+        else:
+            assert torch.isnan(o32).all()               # ... and not written otherwise
+
+
 def test_igemm_split_fp16_1x1():
     """3-pass split-fp16 1x1 conv (a_hi w_hi + a_lo w_hi + a_hi w_lo): fp32 operands to ~2^-22."""
     g = _g(9)

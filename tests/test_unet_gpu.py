@@ -394,3 +394,29 @@ def test_groupnorm_inside_proj_in_is_bit_identical(cfg_name, B, h, w, monkeypatc
     torch.cuda.synchronize()
     assert torch.isfinite(e1).all()
     assert torch.equal(e0, e1), float((e0 - e1).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['sdv1_8x8', 'sdv1_16x16', 'sdv1_64x64', 'sdv1_b6_16x16', 'tiny_16x16'])
+def test_groupnorm_inside_the_splitk_reduction_is_bit_identical(case, golden_dir, monkeypatch):
+    """ResBlock conv1 -> GroupNorm + SiLU -> conv2 (openaimodel.py:225-231) where conv1 is split along K: the reduction applies
+    the GroupNorm itself (splitk_reduce_gn_kernel; default) instead of statistics atomics + a GroupNorm-apply launch
+    (SDMI_REDUCE_GN=0).  The value it normalises is the same fp32 number, the statistics are the same integers (the same per-quad
+    fp32 partials, summed exactly in registers instead of through the fixed-point accumulator words) folded by the same function,
+    the elementwise arithmetic is the same function: eps must not change by one bit -- the parity margin is untouched."""
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg_name = case.split('_')[0]
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, int(z['weight_seed']))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
+    ref = torch.from_numpy(z['eps'])
+    monkeypatch.setenv('SDMI_REDUCE_GN', '1')
+    e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_REDUCE_GN', '0')
+    e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    torch.cuda.synchronize()
+    d1 = float((e1.float().cpu() - ref).abs().max())
+    print(f'[reduce+gn {case}] vs reference {d1:.3e}; vs the two launches {float((e1 - e0).abs().max()):.3e}', flush=True)
+    assert d1 <= TOL
+    assert torch.equal(e1, e0), float((e1 - e0).abs().max())

@@ -232,6 +232,42 @@ def install_stubs(have_gpu, offline_stubs=False, real_ckpt=False):
 
 
 HIP_COND_STAGE = False
+BUNDLE = os.path.join(REPO, 'oracle', '_ref', 'refbundle')     # oracle/build_ref_bundle.py (git-ignored build output)
+
+
+def _inference_yaml_text(ref):
+    """configs/stable-diffusion/v1-inference.yaml of a checkout, or the same content re-serialised from the bundle's parsed copy."""
+    src = os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')
+    if os.path.exists(src):
+        return open(src).read()
+    import json
+    import yaml
+    with open(os.path.join(ref, 'v1-inference.json')) as f:
+        return yaml.safe_dump(json.load(f), default_flow_style=False, sort_keys=False)
+
+
+def _report_hip_calls():
+    """--hip: count the forwards that reach libsdmi and say so at exit (the evidence that the script drove the HIP path)."""
+    import atexit
+    from stable_diffusion_amd import unet as _u, vae as _v, clip as _c
+    counts = {'UNetModelHIP.forward': 0, 'AutoencoderKLHIP.decode': 0, 'FrozenCLIPEmbedderHIP.forward': 0}
+
+    def wrap(cls, name, key):
+        real = getattr(cls, name)
+
+        def counted(self, *a, **k):
+            counts[key] += 1
+            return real(self, *a, **k)
+        setattr(cls, name, counted)
+    wrap(_u.UNetModelHIP, 'forward', 'UNetModelHIP.forward')
+    wrap(_v.AutoencoderKLHIP, 'decode', 'AutoencoderKLHIP.decode')
+    wrap(_c.FrozenCLIPEmbedderHIP, 'forward', 'FrozenCLIPEmbedderHIP.forward')
+
+    def report():
+        from stable_diffusion_amd import _lib
+        print('run_reference_script: libsdmi calls -- ' + ', '.join(f'{k} x{v}' for k, v in counts.items()) +
+              f' (library: {_lib.LIB_PATH})', flush=True)
+    atexit.register(report)
 
 
 def patch_torch_load():
@@ -264,7 +300,11 @@ def main():
     args = ap.parse_args()
     rest = args.rest[1:] if args.rest[:1] == ['--'] else args.rest
     ref = os.path.abspath(args.reference)
-    assert os.path.isdir(os.path.join(ref, 'ldm')), f'reference checkout not found at {ref}'
+    if not os.path.isdir(os.path.join(ref, 'ldm')) and os.path.isdir(os.path.join(BUNDLE, 'ldm')):
+        # a GPU box: no reference checkout, but the bytecode bundle oracle/build_ref_bundle.py compiled from it travelled with the repo
+        print(f'run_reference_script: no reference checkout at {ref}; using the bytecode bundle {BUNDLE}', file=sys.stderr)
+        ref = BUNDLE
+    assert os.path.isdir(os.path.join(ref, 'ldm')), f'reference checkout not found at {ref} (and no bundle at {BUNDLE})'
     sys.path.insert(0, ref)
     have_gpu = torch.cuda.is_available()
     if args.hip and not have_gpu:
@@ -280,8 +320,7 @@ def main():
         from stable_diffusion_amd import DDIMSamplerHIP, DPMSolverSamplerHIP, PLMSSamplerHIP
         import ldm.models.diffusion.dpm_solver as dpm
         plms.PLMSSampler, ddim.DDIMSampler, dpm.DPMSolverSampler = PLMSSamplerHIP, DDIMSamplerHIP, DPMSolverSamplerHIP
-        src = os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')
-        text = open(src).read()
+        text = _inference_yaml_text(ref)
         old = 'target: ldm.modules.diffusionmodules.openaimodel.UNetModel'
         assert old in text
         tmp = tempfile.NamedTemporaryFile('w', suffix='-mi355x.yaml', delete=False)
@@ -309,10 +348,20 @@ def main():
             _init(self, *a, **k)
         enc.FrozenCLIPEmbedder.__init__ = _cpu_init
     if '--config' not in rest:
-        rest = ['--config', os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')] + rest
+        plain = os.path.join(ref, 'configs', 'stable-diffusion', 'v1-inference.yaml')
+        if not os.path.exists(plain):       # the bundle holds the parsed config only
+            tmp = tempfile.NamedTemporaryFile('w', suffix='-v1-inference.yaml', delete=False)
+            tmp.write(_inference_yaml_text(ref))
+            tmp.close()
+            plain = tmp.name
+        rest = ['--config', plain] + rest
     script = os.path.join(ref, 'scripts', args.script + '.py')
+    if not os.path.exists(script):
+        script += 'c'                       # bytecode bundle: runpy executes a compiled file the same way
     sys.argv = [script] + rest
-    os.chdir(ref if os.access(ref, os.W_OK) else tempfile.mkdtemp())
+    if args.hip:
+        _report_hip_calls()
+    os.chdir(ref if (os.access(ref, os.W_OK) and ref != BUNDLE) else tempfile.mkdtemp())
     runpy.run_path(script, run_name='__main__')
 
 
