@@ -151,7 +151,7 @@ def offline_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic_rNN.json, the newest);
     PMC counters cannot be collected inside this process, so `roofline.traffic` is read from that committed pass."""
     try:
-        path = next(p_ for p_ in (os.path.join(ROOT, 'profiles', f'traffic_r0{r}.json') for r in (3, 2)) if os.path.exists(p_))
+        path = next(p_ for p_ in (os.path.join(ROOT, 'profiles', f'traffic_r0{r}.json') for r in (4, 3, 2)) if os.path.exists(p_))
         d = json.load(open(path))
         k = d['kernels'].get(kernel_class)
         if k:
@@ -172,7 +172,7 @@ def traffic_pass(out_json=None, keep_dir=None, also=None):
     import sqlite3
     import subprocess
     import tempfile
-    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r03.json')
+    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r04.json')
     work = keep_dir or tempfile.mkdtemp(prefix='sdmi_traffic_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     per = {}
@@ -341,7 +341,7 @@ def main():
                     help='txt2img512 = BASELINE.json configs[1] (the headline metric, default); txt2img768 = configs[3]; '
                          'img2img512 = configs[4]')
     ap.add_argument('--traffic-pass', action='store_true',
-                    help='measure HBM bytes per launch with rocprofv3 PMC passes and write profiles/traffic_r02.json (then exit)')
+                    help='measure HBM bytes per launch with rocprofv3 PMC passes and write profiles/traffic_r04.json (then exit)')
     ap.add_argument('--traffic-out', default=None, help='second copy of the --traffic-pass JSON (e.g. under gpurun_out/)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the CPU comparator (no GPU needed) and exit')
     args = ap.parse_args()

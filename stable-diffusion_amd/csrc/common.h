@@ -89,12 +89,17 @@ enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 #else
 #define SDMI_ST(T, ptr, val) (*(T*)(ptr) = (T)(val))
 #endif
-// -DSDMI_WT_STORES=1|2 (round-4 experiment, same question): the 16-byte fp32 output stores (=2: the 8-byte fp16 ones as well)
-// carry the sc1 bit, i.e. they are written THROUGH the XCD's L2 while the kernel runs instead of sitting dirty in it until the
-// end-of-kernel write-back (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s; `nt` is not write-through, sc1 is; a
-// 16-byte sc1 store costs what a plain one does, narrower ones are one fabric write each).  base = wave-uniform tensor base,
-// off = element offset (byte offset < 2^31: checked by the launchers' workspace sizes).
-#if defined(__HIPCC__) && defined(SDMI_WT_STORES)
+// Write-through output stores (round 4, default): the 16-byte fp32 output stores of the GEMM epilogues, the split-K reduce and
+// GroupNorm-apply carry the sc1 bit, i.e. they are written THROUGH the XCD's L2 while the kernel runs instead of sitting dirty in
+// it until the end-of-kernel write-back (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s; `nt` is not write-through,
+// sc1 is; a 16-byte sc1 store costs what a plain one does, narrower ones are one fabric write each).  Same values, same addresses:
+// bit-identical.  Same-box A/B (profiles/wt_stores_r04.txt): -0.03 ms per UNet call (-0.5 %), first-stage decode unchanged;
+// -DSDMI_WT_STORES=2 (the 8-byte fp16 stores as well) measured the same as 1, -DSDMI_WT_STORES=0 = plain stores.
+// base = wave-uniform tensor base, off = element offset (byte offset < 2^31: every tensor here is far below 2 GB).
+#ifndef SDMI_WT_STORES
+#define SDMI_WT_STORES 1
+#endif
+#if defined(__HIPCC__) && SDMI_WT_STORES >= 1
 typedef unsigned sdmi_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sdmi_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sdmi_st_wt16(const void* base, size_t byte_off, f32x4 v) {

@@ -579,8 +579,11 @@ static int reduce_gn_maxq(const IGemmParams& p, int nsplit) {
   const int on = env_int("SDMI_REDUCE_GN", 1);      // (read per launch: the tests flip it between two forwards)
   const int hw = p.Hout * p.Wout;
   if (!on || !p.pgn_out || !p.pgn_gamma || !p.pgn_beta || p.mode != EPI_PLAIN || nsplit < 2 || nsplit > 16) return 0;
-  if (p.N % 128 || p.M != p.B * hw || p.out_f16 || p.out_lo || p.ln_out || p.lnp_out || p.gn_n > 1) return 0;
-  if (p.gn_n == 1 && (p.gn_cbase[0] != 0 || p.gn_cpg[0] != p.N / 32)) return 0;      // statistics wanted by some OTHER GroupNorm
+  if (p.N % 128 || p.M != p.B * hw || p.out_f16 || p.out_lo || p.ln_out || p.lnp_out) return 0;
+  // Taken only where the two-launch path gets that GroupNorm's statistics from this very reduction (the executor attached it as the
+  // one statistics target: Hout*Wout % 32 == 0, ...): the result is then the same bits (see the kernel), i.e. this is a launch-count
+  // optimisation with no numerical footprint.  Elsewhere (maps of < 32 pixels) the statistics kernel + apply launches stay.
+  if (p.gn_n != 1 || p.gn_cbase[0] != 0 || p.gn_cpg[0] != p.N / 32 || hw % 32) return 0;
   if (p.pgn_keep_f32 && (!p.out_f32 || p.ldo % 4)) return 0;
   if (p.ldr % 4 || p.ld_rowvec % 4) return 0;
   if (reduce_rows_per_block(p) != 32) return 0;         // (the statistics are then the two-launch path's, bit for bit: see the kernel)

@@ -231,7 +231,7 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   if (!p.skip_stats) hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
   if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
     const int64_t quads = (int64_t)p.HW * (C / 4);
-    static const int64_t u4_from = getenv("SDMI_GN_APPLY_U4_QUADS") ? atoll(getenv("SDMI_GN_APPLY_U4_QUADS")) : ((int64_t)1 << 20);   // A/B knob
+    static const int64_t u4_from = getenv("SDMI_GN_APPLY_U4_QUADS") ? atoll(getenv("SDMI_GN_APPLY_U4_QUADS")) : 300000;   // A/B knob; default: the 64x64 level of the 512 x 512 workload (327 680 quads per sample at 320 channels) and everything larger -- round 4, same-box A/B -0.03 ms per UNet call, 32x32 maps and below measured no gain (profiles/wt_stores_r04.txt)
     const int nq = C / 4;
     // multiply-shift division needs (quad index + a block's overshoot) * divisor < 2^40
     const unsigned long long magic_nq = ((quads + 1024) * (int64_t)nq < ((int64_t)1 << 40) && quads + 1024 < ((int64_t)1 << 31)) ? gn_div_magic(nq) : 0ull;

@@ -278,8 +278,14 @@ def test_igemm_splitk_reduce_applies_groupnorm(B, H, W, C, N, splitk, tile, ksiz
     for rep in range(4):
         o16 = torch.full((B * H * W, N), float('nan'), dtype=torch.float16, device=DEV)
         o32 = torch.full((B * H * W, N), float('nan'), device=DEV)
+        # (the executor's situation: that GroupNorm is the output's one statistics target -- the condition under which the
+        # reduction may apply it, because only then is the result the two-launch path's, bit for bit)
+        acc = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
         applied = K.igemm(a_d, wp, N, B, H, W, H, W, ksize, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=o32,
-                          splitk=splitk, tile=tile, fused_splitk=False, pgn=(ga_d, be_d, 1e-5, 1, o16, rep % 2))
+                          splitk=splitk, tile=tile, fused_splitk=False, pgn=(ga_d, be_d, 1e-5, 1, o16, rep % 2),
+                          gn=[(acc, N // 32, 0)])
+        if applied:
+            assert int(acc.abs().sum().item()) == 0        # no statistics atomics: the group never leaves the workgroup
         outs.append((applied, o16, o32))
     torch.cuda.synchronize()
     applied = outs[0][0]
