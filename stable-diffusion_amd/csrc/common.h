@@ -184,6 +184,13 @@ struct IGemmParams {
   int dbg_abl = 0;                                     // timing build only (SDMI_EPI_ABL): 1 no residual loads, 2 no GroupNorm statistics, 4 no output stores
 #endif
   int splitk_fused = 0;                                // set by the launcher
+  // set by the launcher (round 4): the unfused split-K slabs hold whole TILES in the MFMA register order -- slab float index
+  // ((split * ntiles + tile) * BM * BN) + ((i * TN + j) * 4 + r4) * (NT * 4) + thread * 4 + e -- instead of [split][M][N]: a lane
+  // stores its 4 consecutive accumulator rows of a column as ONE 16-byte write-through store (a wave writes 1 KB runs; the
+  // row-major layout takes 4-byte stores, 128-byte runs), and splitk_reduce_tiled_kernel turns 4 x 4 blocks between 4 adjacent
+  // lanes back into row-major quads.  slab_bm / bn / wm / wn: the tile geometry the reduction needs to decode it.
+  int slab_tiled = 0, slab_bm = 0, slab_bn = 0, slab_wm = 0, slab_wn = 0;
+  int slab_sh_qpt = 0, slab_sh_nt = 0, slab_sh_tn = 0, slab_sh_wn = 0;      // log2 of BM * BN / 4, threads, TN, WARPS_N
   int epi_vec = 0;                                     // set by the launcher: 16-byte epilogue (pointer / pitch alignment checked there)
   int tile_n_fastest = 0;                              // set by the launcher: tile numbering inside an XCD's range
   const f16* zero_page = nullptr;                      // >= 16 bytes of zeros (for out-of-image taps)

@@ -473,6 +473,24 @@ __global__ void __launch_bounds__(256) splitk_reduce_heads_kernel(IGemmParams p,
   }
 }
 
+// 4 x 4 transpose between the four lanes of a quad: in, lane (sub = lane & 3) holds v[e] = element (row e, column sub) of a 4 x 4
+// block; out, it holds w[c] = element (row sub, column c).  Round k: every lane offers v[(sub + k) & 3], lane d takes the offer of
+// lane (d - k) & 3 -- DPP quad_perm, a VALU modifier: no LDS traffic.
+__device__ __forceinline__ float pick4(const f32x4 v, int idx) {
+  return idx == 0 ? v[0] : (idx == 1 ? v[1] : (idx == 2 ? v[2] : v[3]));
+}
+template <int CTRL>
+__device__ __forceinline__ float quad_dpp(float x) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ f32x4 quad_transpose(const f32x4 v, int sub) {
+  const float r0 = pick4(v, sub);
+  const float r1 = quad_dpp<0x93>(pick4(v, (sub + 1) & 3));      // quad_perm [3, 0, 1, 2]: lane d reads lane d - 1
+  const float r2 = quad_dpp<0x4E>(pick4(v, (sub + 2) & 3));      // [2, 3, 0, 1]
+  const float r3 = quad_dpp<0x39>(pick4(v, (sub + 3) & 3));      // [1, 2, 3, 0]
+  const f32x4 r = {r0, r1, r2, r3};                               // r[k] = element (row sub, column (sub - k) & 3)
+  return f32x4{pick4(r, sub & 3), pick4(r, (sub - 1) & 3), pick4(r, (sub - 2) & 3), pick4(r, (sub - 3) & 3)};
+}
 // Split-K reduction + GroupNorm(32) (+ SiLU) of the result in ONE launch (IGemmParams::pgn_*; ResBlock conv1 -> out_layers'
 // GroupNorm -> SiLU, openaimodel.py:225-231, at the levels where conv1 is split: 8x8, 16x16, the concat blocks of 32x32).
 // Workgroup (g, b) owns group g of sample b: HW rows x cpg = N / 32 channels.  Thread t handles the 16-byte quads t, t + 1024, ...
@@ -491,25 +509,51 @@ __device__ __forceinline__ void quad_partials(const f32x4 a, float* q1, float* q
   const float s0 = a[0] * a[0], s1 = a[1] * a[1], s2 = a[2] * a[2], s3 = a[3] * a[3];
   *q2 = ((s0 + s1) + s2) + s3;
 }
-template <int MAXQ>
+// TILED: the slabs hold whole tiles in the MFMA register order (IGemmParams::slab_tiled).  Thread idx then loads the slab quad
+// (4 rows x 1 column) of row group idx / cpg, column idx % cpg -- four consecutive threads = four consecutive columns of the same
+// four rows (cpg % 4 == 0), a run of <= 32 columns is <= 512 contiguous bytes -- and the 4 x 4 lane transpose hands every lane the
+// row-major quad (row 4 * (idx / cpg) + (idx & 3), columns 4 * ((idx % cpg) / 4) ..).  Which thread holds which quad does not matter
+// to anything below (integer statistics, stores).
+template <int MAXQ, bool TILED>
 __global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(IGemmParams p, int nsplit, unsigned long long magic_qpr) {
   __shared__ long long s_red[16][4];
   const int g = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
   const int HW = p.Hout * p.Wout;
   const int cpg = p.N >> 5, qpr = cpg >> 2;
   const int total = HW * qpr;
-  const size_t slab_sz = (size_t)p.M * p.N;
+  const size_t slab_sz = TILED ? (size_t)(((p.M + p.slab_bm - 1) / p.slab_bm) * ((p.N + p.slab_bn - 1) / p.slab_bn)) * (size_t)(p.slab_bm * p.slab_bn)
+                               : (size_t)p.M * p.N;
   f32x4 v[MAXQ];
+  int rown[MAXQ][2];                                    // the quad this thread holds: row inside the sample, first column
   long long w[4] = {0, 0, 0, 0};                       // {sum int, sum frac, sumsq int, sumsq frac} of this thread's quads
 #pragma unroll
   for (int i = 0; i < MAXQ; ++i) {
     const int idx = tid + i * 1024;
     v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    if (idx < total) {
-      const int row = fast_div(idx, magic_qpr);
-      const int n = g * cpg + (idx - row * qpr) * 4;
+    rown[i][0] = 0; rown[i][1] = g * cpg;
+    if (idx < total) {                                   // (total % 4 == 0 and idx % 4 == lane % 4: a lane quad is inside or outside as a whole)
+      int row, n;
+      const float* src;
+      if (TILED) {
+        const int row4 = fast_div(idx, p.gn_magic[0]);   // idx / cpg (the launcher checked gn_cpg[0] == cpg)
+        const int c = idx - row4 * cpg;
+        const int m4 = b * HW + 4 * row4, nc = g * cpg + c;
+        const int BM = p.slab_bm, BN = p.slab_bn, WTM = BM / p.slab_wm, WTN = BN >> p.slab_sh_wn;
+        const int tiles_n = (p.N + BN - 1) / BN;
+        const int tile_m = m4 / BM, mm = m4 - tile_m * BM, wm = mm / WTM, mw = mm - wm * WTM, ii = mw >> 5, r32 = mw & 31;
+        const int tile_n = nc / BN, nn = nc - tile_n * BN, wn = nn / WTN, nw = nn - wn * WTN, jj = nw >> 5, l31 = nw & 31;
+        const int blk = (((ii << p.slab_sh_tn) + jj) << 2) + (r32 >> 3);
+        const int t_in = (((wm << p.slab_sh_wn) + wn) << 6) + (((r32 >> 2) & 1) << 5) + l31;
+        src = p.splitk_ws + (size_t)(tile_m * tiles_n + tile_n) * (size_t)(BM * BN) + (((size_t)blk << p.slab_sh_nt) + t_in) * 4;
+        row = 4 * row4 + (tid & 3);
+        n = g * cpg + (c & ~3);
+      } else {
+        row = fast_div(idx, magic_qpr);
+        n = g * cpg + (idx - row * qpr) * 4;
+        src = p.splitk_ws + ((size_t)b * HW + row) * p.N + n;
+      }
+      rown[i][0] = row; rown[i][1] = n;
       const size_t m = (size_t)b * HW + row;
-      const float* src = p.splitk_ws + m * p.N + n;
       f32x4 biasv = {0.f, 0.f, 0.f, 0.f}, rvv = {0.f, 0.f, 0.f, 0.f}, resv = {0.f, 0.f, 0.f, 0.f};
       if (p.bias) biasv = *(const f32x4*)(p.bias + n);
       if (p.rowvec) rvv = *(const f32x4*)(p.rowvec + (size_t)b * p.ld_rowvec + n);
@@ -520,6 +564,7 @@ __global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(IGemmParams p, i
       f32x4 a = part[0];
 #pragma unroll
       for (int s = 1; s < 16; ++s) a += part[s];       // fixed order; absent splits add +0
+      if (TILED) a = quad_transpose(a, tid & 3);       // (all four lanes of a quad are in this branch together)
       a += biasv;
       if (p.rowvec) a += rvv;
       if (p.residual) a += resv;
@@ -554,9 +599,8 @@ __global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(IGemmParams p, i
   for (int i = 0; i < MAXQ; ++i) {
     const int idx = tid + i * 1024;
     if (idx < total) {
-      const int row = fast_div(idx, magic_qpr);
-      const int n = g * cpg + (idx - row * qpr) * 4;
-      const size_t m = (size_t)b * HW + row;
+      const int n = rown[i][1];
+      const size_t m = (size_t)b * HW + rown[i][0];
       const f32x4 ga = *(const f32x4*)(p.pgn_gamma + n), be = *(const f32x4*)(p.pgn_beta + n);
       f16x4 y;
 #pragma unroll
@@ -566,29 +610,139 @@ __global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(IGemmParams p, i
   }
 }
 
-// rows per block of splitk_reduce_kernel: 32 (one row per thread) up to 256, doubling while the grid keeps >= 1024 blocks
-static int reduce_rows_per_block(const IGemmParams& p) {
-  int rpb = 32;
-  const int hw = p.Hout * p.Wout;
-  while (rpb < 256 && (int64_t)cdiv(p.N / 4, 8) * cdiv(p.M, rpb * 2) >= 1024 && (p.gn_n == 0 || hw % (rpb * 2) == 0)) rpb *= 2;
-  return rpb;
+// ---- reduction over register-order slabs (IGemmParams::slab_tiled) -------------------------------------------------------
+// a quad's statistics partials as splitk_reduce_kernel forms them with one row per thread: channels j < gsplit belong to the first
+// group, the rest to the next; plain adds over the values and over the ROUNDED squares (no fused multiply-add)
+__device__ __forceinline__ void quad_partials_split(const f32x4 v, int gsplit, float* a1, float* a2, float* c1, float* c2) {
+#pragma clang fp contract(off)
+  float s1 = 0.f, s2 = 0.f, t1 = 0.f, t2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float sq = v[j] * v[j];
+    if (j < gsplit) { s1 += v[j]; s2 += sq; } else { t1 += v[j]; t2 += sq; }
+  }
+  *a1 = s1; *a2 = s2; *c1 = t1; *c2 = t2;
+}
+// where thread `rem` (0 .. BM * BN / 4) of tile `tile` finds its quad, and which output quad it owns after the transpose
+struct TiledQuad { size_t off; int m, n; bool valid; };
+__device__ __forceinline__ TiledQuad tiled_quad(const IGemmParams& p, int q, int lane) {
+  const int BM = p.slab_bm, BN = p.slab_bn;
+  const int WTM = BM / p.slab_wm, WTN = BN >> p.slab_sh_wn;
+  const int tiles_n = (p.N + BN - 1) / BN;
+  const int tile = q >> p.slab_sh_qpt, rem = q - (tile << p.slab_sh_qpt);       // (every divisor but tiles_n is a power of two)
+  const int blk = rem >> p.slab_sh_nt, t_in = rem - (blk << p.slab_sh_nt);
+  const int wave = t_in >> 6;
+  const int ij = blk >> 2, r4 = blk & 3, i = ij >> p.slab_sh_tn, j = ij - (i << p.slab_sh_tn);
+  const int wm = wave >> p.slab_sh_wn, wn = wave - (wm << p.slab_sh_wn);
+  const int tile_m = tile / tiles_n, tile_n = tile - tile_m * tiles_n;
+  const int l31 = lane & 31, lg = lane >> 5;
+  TiledQuad t;
+  t.off = (size_t)tile * (size_t)(BM * BN) + (size_t)rem * 4;
+  t.m = tile_m * BM + wm * WTM + i * 32 + 8 * r4 + 4 * lg + (l31 & 3);
+  t.n = tile_n * BN + wn * WTN + j * 32 + (l31 & ~3);
+  t.valid = t.m < p.M && t.n < p.N;
+  return t;
+}
+// out = sum_s slab[s] + bias + rowvec[batch] + residual: the arithmetic (and with one row per thread the statistics partials) of
+// splitk_reduce_kernel, value by value.  A block = 256 consecutive slab quads = four GEMM waves' share of one 32-row slab each, so a
+// wave's rows lie inside one sample: the statistics are combined per wave in LDS and leave as one atomic set per (wave, group).
+__global__ void __launch_bounds__(256) splitk_reduce_tiled_kernel(IGemmParams p, int nsplit) {
+  __shared__ unsigned long long s_gn[2][4][32][GN_WORDS];        // [target][wave][group]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const bool gn = p.gn_n > 0;
+  if (gn) {
+    for (int i = tid; i < 2 * 4 * 32 * GN_WORDS; i += 256) (&s_gn[0][0][0][0])[i] = 0ull;
+    __syncthreads();
+  }
+  const TiledQuad t = tiled_quad(p, blockIdx.x * 256 + tid, lane);
+  const int ntiles = ((p.M + p.slab_bm - 1) / p.slab_bm) * ((p.N + p.slab_bn - 1) / p.slab_bn);
+  const size_t split_stride = (size_t)ntiles * (size_t)(p.slab_bm * p.slab_bn);
+  const float* src = p.splitk_ws + t.off;
+  const int HW = p.Hout * p.Wout;
+  const int m = min(t.m, p.M - 1), n = min(t.n, p.N - 4);        // (clamped: every load below is in bounds; stores are masked)
+  f32x4 biasv = {0.f, 0.f, 0.f, 0.f}, rvv = {0.f, 0.f, 0.f, 0.f}, resv = {0.f, 0.f, 0.f, 0.f};
+  if (p.bias) biasv = *(const f32x4*)(p.bias + n);
+  if (p.rowvec) rvv = *(const f32x4*)(p.rowvec + (size_t)(m / HW) * p.ld_rowvec + n);
+  if (p.residual) resv = *(const f32x4*)(p.residual + (size_t)m * p.ldr + n);
+  f32x4 part[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * split_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 a = part[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s) a += part[s];       // fixed order; absent splits add +0 (element-wise: the transpose commutes with it)
+  f32x4 v = quad_transpose(a, lane & 3);
+  v += biasv;
+  if (p.rowvec) v += rvv;
+  if (p.residual) v += resv;
+  if (t.valid) {
+    if (p.out_f32) SDMI_ST_F32X4(p.out_f32, (size_t)m * p.ldo + n, v);
+    if (p.out_f16) SDMI_ST_F16X4(p.out_f16, (size_t)m * p.ldo + n, (f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}));
+    if (p.out_lo) {
+      f16x4 lo;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lo[j] = (f16)(v[j] - (float)(f16)v[j]);
+      *(f16x4*)(p.out_lo + (size_t)m * p.ldo + n) = lo;
+    }
+  }
+  if (gn) {
+    if (t.valid) {
+      for (int tg = 0; tg < p.gn_n; ++tg) {
+        const int c = p.gn_cbase[tg] + n;
+        const int g0 = fast_div(c, p.gn_magic[tg]), g1 = fast_div(c + 3, p.gn_magic[tg]);
+        const int gsplit = (g0 + 1) * p.gn_cpg[tg] - c;              // first of the 4 channels that belongs to g1
+        float a1, a2, c1, c2;
+        quad_partials_split(v, gsplit, &a1, &a2, &c1, &c2);
+        gn_acc_add(&s_gn[tg][wv][g0][0], a1);
+        gn_acc_add(&s_gn[tg][wv][g0][2], a2);
+        if (g1 != g0) { gn_acc_add(&s_gn[tg][wv][g1][0], c1); gn_acc_add(&s_gn[tg][wv][g1][2], c2); }
+      }
+    }
+    __syncthreads();
+    const int slot = blockIdx.x & (GN_SLOTS - 1);
+    for (int e = tid; e < p.gn_n * 4 * 32 * GN_WORDS; e += 256) {
+      const unsigned long long w = (&s_gn[0][0][0][0])[e];
+      if (w == 0ull) continue;
+      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, w4 = (e / (GN_WORDS * 32)) % 4, tg = e / (GN_WORDS * 32 * 4);
+      // the sample of that wave's 32-row slab: its first row (lane 0 of the wave would own it)
+      const TiledQuad t0 = tiled_quad(p, blockIdx.x * 256 + w4 * 64, 0);
+      if (t0.m >= p.M) continue;
+      const int b = t0.m / HW;
+      atomicAdd((unsigned long long*)p.gn_acc[tg] + ((size_t)(b * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
+    }
+  }
 }
 
-// may the reduction of this split GEMM apply the consuming GroupNorm itself (IGemmParams::pgn_*)?  SDMI_REDUCE_GN=0: never (A/B)
-static int reduce_gn_maxq(const IGemmParams& p, int nsplit) {
-  const int on = env_int("SDMI_REDUCE_GN", 1);      // (read per launch: the tests flip it between two forwards)
-  const int hw = p.Hout * p.Wout;
-  if (!on || !p.pgn_out || !p.pgn_gamma || !p.pgn_beta || p.mode != EPI_PLAIN || nsplit < 2 || nsplit > 16) return 0;
-  if (p.N % 128 || p.M != p.B * hw || p.out_f16 || p.out_lo || p.ln_out || p.lnp_out) return 0;
-  // Taken only where the two-launch path gets that GroupNorm's statistics from this very reduction (the executor attached it as the
-  // one statistics target: Hout*Wout % 32 == 0, ...): the result is then the same bits (see the kernel), i.e. this is a launch-count
-  // optimisation with no numerical footprint.  Elsewhere (maps of < 32 pixels) the statistics kernel + apply launches stay.
-  if (p.gn_n != 1 || p.gn_cbase[0] != 0 || p.gn_cpg[0] != p.N / 32 || hw % 32) return 0;
-  if (p.pgn_keep_f32 && (!p.out_f32 || p.ldo % 4)) return 0;
-  if (p.ldr % 4 || p.ld_rowvec % 4) return 0;
-  if (reduce_rows_per_block(p) != 32) return 0;         // (the statistics are then the two-launch path's, bit for bit: see the kernel)
-  const int64_t quads = (int64_t)hw * (p.N / 128);
-  return quads <= 1024 ? 1 : quads <= 3 * 1024 ? 3 : quads <= 5 * 1024 ? 5 : 0;
+// the same reduction for the per-head scatter epilogue: quad (m, n..n+3) lies inside one head (dh % 4 == 0)
+__global__ void __launch_bounds__(256) splitk_reduce_tiled_heads_kernel(IGemmParams p, int nsplit) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const TiledQuad t = tiled_quad(p, blockIdx.x * 256 + tid, lane);
+  const int ntiles = ((p.M + p.slab_bm - 1) / p.slab_bm) * ((p.N + p.slab_bn - 1) / p.slab_bn);
+  const size_t split_stride = (size_t)ntiles * (size_t)(p.slab_bm * p.slab_bn);
+  const float* src = p.splitk_ws + t.off;
+  f32x4 part[16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) part[s] = (s < nsplit) ? *(const f32x4*)(src + s * split_stride) : f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x4 a = part[0];
+#pragma unroll
+  for (int s = 1; s < 16; ++s) a += part[s];
+  f32x4 v = quad_transpose(a, lane & 3);
+  if (!t.valid) return;
+  const int m = t.m, n = t.n;
+  if (p.bias) v += *(const f32x4*)(p.bias + n);
+  const int seg = n / p.segC;
+  const int c = n - seg * p.segC;
+  const int head = c / p.dh;
+  const int dd = c - head * p.dh;
+  const int b = m / p.ntok;
+  const int tok = m - b * p.ntok;
+  const size_t bh = (size_t)b * p.heads + head;
+  f16* dst = p.seg_dst[seg];
+  if (p.seg_kind[seg] == 0) {
+    *(f16x4*)(dst + (bh * p.ntok + tok) * p.dh + dd) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dst[(bh * p.dh + dd + j) * p.ntok_pad + tok] = (f16)v[j];
+  }
 }
 
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
@@ -601,6 +755,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   q.splitk = nsplit;
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
+  slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
   q.magic_hw = div_magic(p.Hout * p.Wout);
@@ -652,13 +807,37 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     const double mn = (double)p.M * p.N;
     ProfScope psg("splitk_reduce_gn", 0.0, mn * 4.0 * nsplit + mn * 2.0 + (p.residual ? mn * 4.0 : 0.0) + (p.pgn_keep_f32 ? mn * 4.0 : 0.0), stream);
     const dim3 grid(32, (unsigned)p.B), block(1024);
-    if (maxq == 1) hipLaunchKernelGGL(splitk_reduce_gn_kernel<1>, grid, block, 0, stream, p, nsplit, magic_qpr);
-    else if (maxq == 3) hipLaunchKernelGGL(splitk_reduce_gn_kernel<3>, grid, block, 0, stream, p, nsplit, magic_qpr);
-    else hipLaunchKernelGGL(splitk_reduce_gn_kernel<5>, grid, block, 0, stream, p, nsplit, magic_qpr);
+    if (p.slab_tiled) {
+      if (maxq == 1) hipLaunchKernelGGL((splitk_reduce_gn_kernel<1, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else if (maxq == 3) hipLaunchKernelGGL((splitk_reduce_gn_kernel<3, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else hipLaunchKernelGGL((splitk_reduce_gn_kernel<5, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
+    } else {
+      if (maxq == 1) hipLaunchKernelGGL((splitk_reduce_gn_kernel<1, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else if (maxq == 3) hipLaunchKernelGGL((splitk_reduce_gn_kernel<3, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else hipLaunchKernelGGL((splitk_reduce_gn_kernel<5, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
+    }
     SDMI_HIP_OK(hipGetLastError());
     psg.end();
     if (p.pgn_applied) *p.pgn_applied = 1;
     if (range_check_enabled() && range_scan("GroupNorm fp16 output (split-K reduction)", p.pgn_out, (int64_t)p.M * p.N, stream)) return -1;
+    return 0;
+  }
+  if (p.slab_tiled) {                  // register-order slabs: one thread per slab quad, whole tiles (padding rows / columns masked)
+    const int64_t quads = (int64_t)cdiv(p.M, p.slab_bm) * cdiv(p.N, p.slab_bn) * (p.slab_bm * p.slab_bn / 4);
+    SDMI_CHECK(quads % 256 == 0 && quads / 256 < (1ll << 31) && p.slab_wm > 0 && p.slab_wn > 0, "tiled split-K slabs: bad geometry");
+    const double mn = (double)p.M * p.N;
+    if (p.mode == EPI_HEADS) {
+      ProfScope psh("splitk_reduce", 0.0, mn * (4.0 * nsplit + 2.0), stream);
+      hipLaunchKernelGGL(splitk_reduce_tiled_heads_kernel, dim3((unsigned)(quads / 256)), dim3(256), 0, stream, p, nsplit);
+      SDMI_HIP_OK(hipGetLastError());
+      return 0;
+    }
+    if (p.gn_n > 0) SDMI_CHECK((p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
+    ProfScope pst("splitk_reduce", 0.0, mn * 4.0 * (nsplit + 1), stream);
+    hipLaunchKernelGGL(splitk_reduce_tiled_kernel, dim3((unsigned)(quads / 256)), dim3(256), 0, stream, p, nsplit);
+    SDMI_HIP_OK(hipGetLastError());
+    pst.end();
+    if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);
     return 0;
   }
   if (p.mode == EPI_HEADS) {

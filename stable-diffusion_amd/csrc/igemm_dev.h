@@ -246,6 +246,27 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
     }
     __syncthreads();                       // smem[0] is reused below
   }
+  if (p.splitk > 1 && !p.splitk_fused && p.slab_tiled) {
+    // ---- unfused split-K, register-order slabs (IGemmParams::slab_tiled): this split's whole tile, 16 bytes per lane and store,
+    // written through (sc1: the slab is read by another kernel on other XCDs; nothing here reads it back) -- a quarter of the
+    // store instructions of the row-major slab, 1 KB runs per wave instruction.  splitk_reduce_tiled_kernel sums the splits in index
+    // order: the same fp32 additions in the same order as the row-major reduction, i.e. the same output bits.
+    constexpr int SC1 = 16;
+    const int tiles_n_all = (p.N + BN - 1) / BN, ntiles = ((p.M + BM - 1) / BM) * tiles_n_all;
+    const int tile_lin = tile_m * tiles_n_all + tile_n;
+    const __amdgpu_buffer_rsrc_t ws = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(p.splitk_ws + ((size_t)split * ntiles + tile_lin) * (size_t)(BM * BN)), 0, BM * BN * 4, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const f32x4 v = {acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2], acc[i][j][4 * r4 + 3]};
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ws, (tid * 4 + ((i * TN + j) * 4 + r4) * (NT * 4)) * 4, 0, SC1);
+        }
+    return;
+  }
   if (p.lnf_part) {
     // ---- LayerNorm of the A rows folded into this GEMM (IGemmParams::lnf_*): thread i < BM brought {mean, rstd} of row m0 + i
     // (lnf_row_stats, kernel prologue); through an LDS table every lane picks up the rows of its accumulator registers ----
@@ -638,15 +659,61 @@ static int tile_order_n_fastest(const IGemmParams& p) {
 }
 
 // split-K slabs a (tile, split) choice needs, in floats: register-order slabs of whole tiles when the reduction is fused
-// into the GEMM (see igemm_epilogue), [split][M][N] for the separate reduce kernel
+// into the GEMM (see igemm_epilogue) or the slabs are tiled (IGemmParams::slab_tiled), [split][M][N] otherwise
 static bool splitk_fusable(const IGemmParams& p, int bm, int bn) {
   // default off: same-box A/B (profiles/splitk_fused_r02.txt) has the separate reduce kernel ahead, 3.23 vs 3.16 images/s
   static const int env_fused = env_int("SDMI_SPLITK_FUSED", 0);
   return env_fused && p.splitk_cnt && (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn) <= p.splitk_cnt_ints;
 }
+// rows per block of splitk_reduce_kernel: 32 (one row per thread) up to 256, doubling while the grid keeps >= 1024 blocks
+static int reduce_rows_per_block(const IGemmParams& p) {
+  int rpb = 32;
+  const int hw = p.Hout * p.Wout;
+  while (rpb < 256 && (int64_t)cdiv(p.N / 4, 8) * cdiv(p.M, rpb * 2) >= 1024 && (p.gn_n == 0 || hw % (rpb * 2) == 0)) rpb *= 2;
+  return rpb;
+}
+// may the reduction of this split GEMM apply the consuming GroupNorm itself (IGemmParams::pgn_*)?  Returns the quads per thread
+// of splitk_reduce_gn_kernel (1 / 3 / 5) or 0.  Opt-in (SDMI_REDUCE_GN=1): bit-identical and 15 launches fewer, but one workgroup
+// per (sample, group) = 64 workgroups read what the plain reduction spreads over the chip -- same-box A/Bs (profiles/splitk_slabs_r04.txt):
+// -0.01 ms per UNet call against the row-major reduce + GroupNorm-apply launches on a fast box, +0.04 ... +0.17 ms against the
+// register-order reduce + GroupNorm-apply launches (mid / slow box: 24 us per launch there).
+static int reduce_gn_maxq(const IGemmParams& p, int nsplit) {
+  const int on = env_int("SDMI_REDUCE_GN", 0);      // (read per launch: the tests flip it between two forwards)
+  const int hw = p.Hout * p.Wout;
+  if (!on || !p.pgn_out || !p.pgn_gamma || !p.pgn_beta || p.mode != EPI_PLAIN || nsplit < 2 || nsplit > 16) return 0;
+  if (p.N % 128 || p.M != p.B * hw || p.out_f16 || p.out_lo || p.ln_out || p.lnp_out) return 0;
+  // Taken only where the two-launch path gets that GroupNorm's statistics from this very reduction (the executor attached it as the
+  // one statistics target: Hout*Wout % 32 == 0, ...): the result is then the same bits (see the kernel), i.e. this is a launch-count
+  // optimisation with no numerical footprint.  Elsewhere (maps of < 32 pixels) the statistics kernel + apply launches stay.
+  if (p.gn_n != 1 || p.gn_cbase[0] != 0 || p.gn_cpg[0] != p.N / 32 || hw % 32) return 0;
+  if (p.pgn_keep_f32 && (!p.out_f32 || p.ldo % 4)) return 0;
+  if (p.ldr % 4 || p.ld_rowvec % 4) return 0;
+  if (reduce_rows_per_block(p) != 32) return 0;         // (the statistics are then the two-launch path's, bit for bit: see the kernel)
+  const int64_t quads = (int64_t)hw * (p.N / 128);
+  return quads <= 1024 ? 1 : quads <= 3 * 1024 ? 3 : quads <= 5 * 1024 ? 5 : 0;
+}
+// Register-order ("tiled") slabs for the unfused split-K (IGemmParams::slab_tiled): every tile shape of the generic / halo /
+// split-fp16 kernels (power-of-two geometry; not the five-wave tile), plain or per-head epilogue.  With GroupNorm statistics only
+// where the row-major reduction forms one partial per quad (32 rows per block): the statistics words are then the same integers.
+// The reduction that applies the GroupNorm itself reads either layout.  SDMI_SLAB_TILED=0: never (A/B).
+static bool slab_tiled_ok(const IGemmParams& p, int bm, int bn, int nsplit) {
+  const int on = env_int("SDMI_SLAB_TILED", 1);      // (read per launch: the tests flip it)
+  if (!on || nsplit <= 1 || splitk_fusable(p, bm, bn) || p.mode == EPI_GEGLU || p.N % 4) return false;
+  if ((bm & (bm - 1)) || (bn & (bn - 1))) return false;
+  if (p.mode == EPI_PLAIN && p.gn_n > 0 && reduce_rows_per_block(p) != 32) return false;
+  return true;
+}
+static void slab_layout(IGemmParams& q, int bm, int bn, int wm, int wn, int nsplit) {
+  q.slab_tiled = slab_tiled_ok(q, bm, bn, nsplit) ? 1 : 0;
+  q.slab_bm = bm; q.slab_bn = bn; q.slab_wm = wm; q.slab_wn = wn;
+  auto lg2 = [](int v) { int s = 0; while ((1 << s) < v) ++s; return s; };
+  q.slab_sh_qpt = lg2(bm * bn / 4); q.slab_sh_nt = lg2(wm * wn * 64); q.slab_sh_tn = lg2(bn / wn / 32); q.slab_sh_wn = lg2(wn);
+  // (power-of-two geometry: slab_tiled_ok; the threads per block and waves per row of every such tile are powers of two as well)
+  if (q.slab_tiled && (((wm * wn) & (wm * wn - 1)) || (wn & (wn - 1)))) q.slab_tiled = 0;
+}
 static int64_t splitk_ws_need(const IGemmParams& p, int bm, int bn, int nsplit) {
   if (nsplit <= 1) return 0;
-  if (splitk_fusable(p, bm, bn)) return (int64_t)nsplit * cdiv(p.M, bm) * bm * cdiv(p.N, bn) * bn;
+  if (splitk_fusable(p, bm, bn) || slab_tiled_ok(p, bm, bn, nsplit)) return (int64_t)nsplit * cdiv(p.M, bm) * bm * cdiv(p.N, bn) * bn;
   return (int64_t)nsplit * p.M * p.N;
 }
 

@@ -251,12 +251,15 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
     (3, 8, 8, 256, 128, 2, 2, 1, False),          # smallest legal width: 4 channels per group
     (2, 16, 16, 320, 256, 0, -1, 3, False),       # auto split / auto tile: applied or not, the launcher says which
 ])
-def test_igemm_splitk_reduce_applies_groupnorm(B, H, W, C, N, splitk, tile, ksize, resid):
+@pytest.mark.parametrize('tiled', ['1', '0'])
+def test_igemm_splitk_reduce_applies_groupnorm(B, H, W, C, N, splitk, tile, ksize, resid, tiled, monkeypatch):
     """GroupNorm(32) + SiLU of a split-K conv's output applied by its reduction (splitk_reduce_gn_kernel, sdmi_igemm_desc::pgn_*):
     against torch's GroupNorm + SiLU of the fp32 conv result, four bit-identical repeats, and against this library's own
     GroupNorm kernels on the reduction's fp32 output (statistics kernel + apply: same elementwise function, statistics from a
     different partition of the same values -- rounding flips only; the bit-identity with the producers' fused statistics is
     checked on whole UNet calls, tests/test_unet_gpu.py)."""
+    monkeypatch.setenv('SDMI_SLAB_TILED', tiled)      # register-order slabs (default) / row-major slabs: the kernel reads either
+    monkeypatch.setenv('SDMI_REDUCE_GN', '1')         # (opt-in: measured slower than reduce + GroupNorm-apply, DESIGN.md section 4)
     g = _g(91)
     a = _rand16((B * H * W, C), g)
     w = _rand16((N, C, ksize, ksize), g, 1.0 / math.sqrt(ksize * ksize * C))
@@ -313,6 +316,76 @@ def test_igemm_splitk_reduce_applies_groupnorm(B, H, W, C, N, splitk, tile, ksiz
             assert torch.equal(o32, v2)                 # pgn_keep_f32: the reduction's fp32 value, bit for bit
         else:
             assert torch.isnan(o32).all()               # ... and not written otherwise
+
+
+@pytest.mark.parametrize('B,H,W,C,N,splitk,tile,ksize', [
+    (2, 8, 8, 1280, 1280, 12, 19, 3),      # 8x8 level, igemm 64x128 deep ring
+    (2, 16, 16, 1280, 1280, 10, 15, 3),    # halo tile 256x128, 8 waves
+    (2, 16, 16, 640, 1280, 5, 14, 3),      # halo 256x64
+    (2, 32, 32, 320, 320, 3, 10, 3),       # 64x64, 10 channels per group: quads straddle groups
+    (1, 5, 7, 256, 200, 3, 2, 3),          # ragged M and N: padded tiles
+    (3, 4, 8, 64, 200, 2, 8, 3),           # 64x128 tile, N not a tile multiple
+    (2, 16, 16, 1280, 320, 4, 12, 1),      # 64x256 (1 x 4 waves), 1x1
+    (2, 16, 16, 640, 640, 4, 13, 1),       # 256x64 (4 x 1 waves)
+])
+def test_splitk_register_order_slabs_are_bit_identical(B, H, W, C, N, splitk, tile, ksize, monkeypatch):
+    """Unfused split-K with register-order slabs (sdmi::IGemmParams::slab_tiled: 16-byte write-through slab stores, 4 x 4 lane
+    transposes in splitk_reduce_tiled_kernel; default) against the row-major slabs + splitk_reduce_kernel (SDMI_SLAB_TILED=0): the
+    same partial sums added in the same order -- output, fp16 copy and GroupNorm statistics words must not differ by one bit."""
+    g = _g(123)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, ksize, ksize), g, 1.0 / math.sqrt(ksize * ksize * C))
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    resid = torch.randn(B * H * W, N, generator=g)
+    ref = _nhwc(_conv_ref(a, None, w, B, H, W, ksize, 1, 0)) + bias[None] + rowvec.repeat_interleave(H * W, dim=0) + resid
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    a_d, bias_d, rv_d, res_d = a.to(DEV), bias.to(DEV), rowvec.to(DEV), resid.to(DEV)
+    stats = (H * W) % 32 == 0
+    cpg0 = N // 32 if N % 32 == 0 else max(2, N // 20)
+    res = {}
+    for tiled in ('1', '0'):
+        monkeypatch.setenv('SDMI_SLAB_TILED', tiled)
+        out = torch.full((B * H * W, N), float('nan'), device=DEV)
+        o16 = torch.full((B * H * W, N), float('nan'), dtype=torch.float16, device=DEV)
+        acc0 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+        acc1 = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+        K.igemm(a_d, wp, N, B, H, W, H, W, ksize, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=out, out_f16=o16,
+                splitk=splitk, tile=tile, fused_splitk=False,
+                gn=[(acc0, cpg0, 0), (acc1, cpg0 + 4, 3 * cpg0 + 4)] if stats else None)
+        torch.cuda.synchronize()
+        res[tiled] = (out, o16, K.gn_acc_sums(acc0), K.gn_acc_sums(acc1))
+    assert K.report(f'splitk tiled slabs tile{tile} M{B * H * W} N{N}', res['1'][0], ref, 3e-4) < 3e-4
+    assert torch.equal(res['1'][0], res['0'][0]) and torch.equal(res['1'][1], res['0'][1])
+    if stats:
+        for t in (2, 3):
+            assert torch.equal(res['1'][t][0], res['0'][t][0]) and torch.equal(res['1'][t][1], res['0'][t][1])
+
+
+@pytest.mark.parametrize('ntok,d,heads,Kd,splitk,tile', [(256, 160, 8, 1280, 4, -1), (77, 64, 12, 768, 3, 5), (100, 40, 8, 1024, 2, 8)])
+def test_splitk_register_order_slabs_head_scatter_bit_identical(ntok, d, heads, Kd, splitk, tile, monkeypatch):
+    """... and the per-head scatter reduction (q / k rows, v^T columns; ragged token counts: padded tiles)."""
+    g = _g(8)
+    B = 2
+    C = heads * d
+    a = _rand16((B * ntok, Kd), g)
+    w = _rand16((3 * C, Kd), g, 1.0 / math.sqrt(Kd))
+    bias = (torch.randn(3 * C, generator=g) * 0.1).to(DEV)
+    ntp = (ntok + 7) // 8 * 8
+    res = {}
+    for tiled in ('1', '0'):
+        monkeypatch.setenv('SDMI_SLAB_TILED', tiled)
+        q = torch.zeros((B * heads, ntok, d), dtype=torch.float16, device=DEV)
+        k = torch.zeros_like(q)
+        vt = torch.zeros((B * heads, d, ntp), dtype=torch.float16, device=DEV)
+        K.igemm(a.to(DEV), w.to(DEV).contiguous(), 3 * C, B, ntok, 1, ntok, 1, mode=2, bias=bias, splitk=splitk, tile=tile, fused_splitk=False,
+                heads=dict(segs=[(q, 0), (k, 0), (vt, 1)], heads=heads, dh=d, ntok=ntok, ntok_pad=ntp, segC=C))
+        torch.cuda.synchronize()
+        res[tiled] = (q, k, vt)
+    y = (a.float() @ w.float().t() + bias.cpu()).reshape(B, ntok, 3, heads, d)
+    assert K.report('tiled heads q', res['1'][0], y[:, :, 0].permute(0, 2, 1, 3).reshape(B * heads, ntok, d), 4e-3) < 4e-3
+    for i in range(3):
+        assert torch.equal(res['1'][i], res['0'][i])
 
 
 def test_igemm_split_fp16_1x1():

@@ -420,3 +420,23 @@ def test_groupnorm_inside_the_splitk_reduction_is_bit_identical(case, golden_dir
     print(f'[reduce+gn {case}] vs reference {d1:.3e}; vs the two launches {float((e1 - e0).abs().max()):.3e}', flush=True)
     assert d1 <= TOL
     assert torch.equal(e1, e0), float((e1 - e0).abs().max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['sdv1_16x16', 'sdv1_64x64', 'sdv1_b6_16x16', 'tiny_16x16'])
+def test_register_order_splitk_slabs_are_bit_identical(case, golden_dir, monkeypatch):
+    """Unfused split-K slabs in the MFMA register order (16-byte write-through stores, lane transposes in the reduction; default)
+    against the row-major slabs (SDMI_SLAB_TILED=0) on whole UNet calls: eps must not change by one bit."""
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg_name = case.split('_')[0]
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, int(z['weight_seed']))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
+    monkeypatch.setenv('SDMI_SLAB_TILED', '1')
+    e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_SLAB_TILED', '0')
+    e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(e1).all()
+    assert torch.equal(e1, e0), float((e1 - e0).abs().max())
