@@ -89,6 +89,12 @@ enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 #else
 #define SDMI_ST(T, ptr, val) (*(T*)(ptr) = (T)(val))
 #endif
+// Cache policy of the WEIGHT tiles' LDS-DMA loads in the GEMM kernels (igemm / conv3halo / gemm_split16): aux bits of
+// raw_ptr_buffer_load_lds, 0 = default, 2 = nt (MI355X_MICROARCH.md "nt-weights": issued -> landed -18 % on a stream that one CU
+// reads once, -6 % end to end where every CU re-reads the slices).  -DSDMI_W_AUX=2 is a build experiment (round 4).
+#ifndef SDMI_W_AUX
+#define SDMI_W_AUX 0
+#endif
 // Write-through output stores (round 4, default): the 16-byte fp32 output stores of the GEMM epilogues, the split-K reduce and
 // GroupNorm-apply carry the sc1 bit, i.e. they are written THROUGH the XCD's L2 while the kernel runs instead of sitting dirty in
 // it until the end-of-kernel write-back (MI355X_MICROARCH.md: a boundary costs + dirty bytes / 6 TB/s; `nt` is not write-through,

@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
   };
   auto issue_b = [&](int kt, int stage, int q) {
     auto dst = (__attribute__((address_space(3))) void*)(smem + 2 * HALO_BYTES + stage * BSTAGE + (q * RPP + wave_u * 8) * 128);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q], kt * (BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q], kt * (BK * 2), 0, SDMI_W_AUX);
   };
 
   f32x16 acc[TM][TN];
@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_gn_kernel(con
   };
   auto issue_b = [&](int kt, int stage, int q) {
     auto dst = (__attribute__((address_space(3))) void*)(smem + 2 * HALO_BYTES + stage * BSTAGE + (q * RPP + wave_u * 8) * 128);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q], kt * (BK * 2), 0, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q], kt * (BK * 2), 0, SDMI_W_AUX);
   };
 
   // Hand-issued register loads: the compiler does not see them (beside LDS-DMA it would drain the whole ring -- vmcnt(0) -- in

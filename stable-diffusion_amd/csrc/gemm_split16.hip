@@ -83,7 +83,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) gemm_split16_kernel(con
     const unsigned row0 = (isA ? half * BM : 2 * BM + half * BN) + pass * RPP + wave_u * 8;
     auto dst = (__attribute__((address_space(3))) void*)(smem + stage * STAGE_BYTES + row0 * 128);
     if (isA) __builtin_amdgcn_raw_ptr_buffer_load_lds(half ? rsrc_lo : rsrc_hi, dst, 16, a_off[pass], soff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[pass], soff + (half ? w_lo_off : 0), 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[pass], soff + (half ? w_lo_off : 0), 0, SDMI_W_AUX);
   };
 
   const int wm = wave / WARPS_N, wn = wave - wm * WARPS_N;

@@ -209,7 +209,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
     const unsigned row0 = (q < A_PASSES ? q * RPP : BM + (q - A_PASSES) * RPP) + wave_u * 8;
     auto dst = (__attribute__((address_space(3))) void*)(smem + c.lds + row0 * 128);
     if (q < A_PASSES) __builtin_amdgcn_raw_ptr_buffer_load_lds(c.rsrc_a, dst, 16, a_voff(c, q), c.a_soff, 0, 0);
-    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q - A_PASSES], c.b_soff, 0, 0);
+    else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, dst, 16, b_off[q - A_PASSES], c.b_soff, 0, SDMI_W_AUX);
   };
   auto issue_loads = [&](int stage) {
     const TileCursor c = next_tile(stage);
