@@ -197,7 +197,9 @@ typedef struct sdmi_igemm_desc {
   void* seg_dst[3]; int32_t seg_kind[3];
   int32_t heads, dh, ntok, ntok_pad, segC;
   int32_t splitk;                       /* 1 none, 0 auto, >1 forced (plain mode; needs splitk_ws) */
-  float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs (layout: see splitk_cnt) */
+  float* splitk_ws; int64_t splitk_ws_floats;   /* fp32 slabs: scratch, splitk * round_up(M, BM) * round_up(N, BN) floats cover every
+                                                   layout (whole tiles in the MFMA register order -- the default since round 4,
+                                                   SDMI_SLAB_TILED -- or [splitk][M][N]; see also splitk_cnt) */
   int32_t tile;                         /* -1 auto (tuning table); BMxBN/waves/LDS-DMA stages: 0 128x128/4/2, 1 128x64/4/2,
                                            2 64x64/4/2, 3 256x128/8/2, 4 128x64/4/3, 5 64x64/4/3, 6 256x128/8/3, 7 128x128/4/3,
                                            8 64x128/4/3, 9 128x128/8/3, 10 64x64/4/4, 11 128x256/8/2, 12 64x256/4/3, 13 256x64/4/3;
