@@ -106,19 +106,28 @@ static unsigned long long gn_div_magic(int d) { return ((1ull << 40) + (unsigned
 
 // normalise (+SiLU); U channel quads per thread (U = 4 on first-stage-sized maps so the per-block statistics fold is
 // amortised); grid (blocks per batch row, B)
+// xcd_affine: the dispatcher places block L (x fastest) on XCD L % 8; renumbered so that XCD x handles the x-th eighth of the
+// (sample, pixel) range -- the rows a following row-affine GEMM (igemm: "an XCD owns rows of A" when M > N) reads on that same XCD,
+// whose L2 then already holds the fp16 operand this kernel wrote (plain stores stay in the L2).  Speed only; any placement is correct.
 template <int U>
 __global__ void __launch_bounds__(256) gn_apply_kernel(GroupNormParams p, const unsigned long long magic_nq,
-                                                       const unsigned long long magic_cpg) {
+                                                       const unsigned long long magic_cpg, const int xcd_affine) {
   __shared__ float s_mean[32], s_rstd[32];
   const int C = p.c0 + p.c1;
   const int cpg = C / 32;
   const int nq = C / 4;
-  const int b = blockIdx.y, tid = threadIdx.x;
+  int bx = blockIdx.x, by = blockIdx.y;
+  if (xcd_affine) {
+    const int nb = gridDim.x, lin = by * nb + bx, per = (nb * gridDim.y) >> 3;
+    const int wg = (lin & 7) * per + (lin >> 3);
+    by = wg / nb; bx = wg - by * nb;
+  }
+  const int b = by, tid = threadIdx.x;
   // The activation quads (and their gamma / beta) are requested FIRST: they do not depend on the statistics, so their
   // latency runs under the accumulator loads and the fp64 fold below instead of behind them (a block handles 256 * U quads:
   // with U = 1 the fold's round trip was as long as the block's useful work).
   const int64_t total = (int64_t)p.HW * nq;
-  const int64_t base = (int64_t)blockIdx.x * (256 * U) + tid;   // quad index inside this batch row
+  const int64_t base = (int64_t)bx * (256 * U) + tid;           // quad index inside this batch row
   f32x4 v[U], ga[U], be[U]; size_t pix[U]; int ch[U];
 #pragma unroll
   for (int u = 0; u < U; ++u) {
@@ -236,10 +245,15 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     // multiply-shift division needs (quad index + a block's overshoot) * divisor < 2^40
     const unsigned long long magic_nq = ((quads + 1024) * (int64_t)nq < ((int64_t)1 << 40) && quads + 1024 < ((int64_t)1 << 31)) ? gn_div_magic(nq) : 0ull;
     const unsigned long long magic_cpg = gn_div_magic(C / 32);           // (c + 3) * cpg < 2^40 always
-    if (quads >= u4_from)
-      hipLaunchKernelGGL(gn_apply_kernel<4>, dim3((unsigned)((quads + 1023) / 1024), p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg);
-    else
-      hipLaunchKernelGGL(gn_apply_kernel<1>, dim3((unsigned)((quads + 255) / 256), p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg);
+    // XCD-affine block numbering (see the kernel): SDMI_GN_XCD=1, round-4 experiment; needs a block count that is a multiple of 8
+    const int want_xcd = getenv("SDMI_GN_XCD") ? atoi(getenv("SDMI_GN_XCD")) : 0;
+    if (quads >= u4_from) {
+      const unsigned nb = (unsigned)((quads + 1023) / 1024);
+      hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nb, p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg, (want_xcd && (nb * p.B) % 8 == 0) ? 1 : 0);
+    } else {
+      const unsigned nb = (unsigned)((quads + 255) / 256);
+      hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nb, p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg, (want_xcd && (nb * p.B) % 8 == 0) ? 1 : 0);
+    }
   }
   SDMI_HIP_OK(hipGetLastError());
   if (range_check_enabled()) {
