@@ -6,8 +6,8 @@ P=${1:-j}
 O=$PWD/gpurun_out; mkdir -p $O
 L=$PWD/stable-diffusion_amd
 T0=$(date +%s); el() { echo "[t+$(( $(date +%s) - T0 ))s] $*"; }
-cp tools/gpu_scripts/.i_tune_r4.txt $O/${P}_tune_i.txt
-cp tools/gpu_scripts/.i_tune_r4.txt $O/${P}_tune.txt
+cp ${TUNE_I:-$L/tune_gfx950.txt} $O/${P}_tune_i.txt
+cp ${TUNE_I:-$L/tune_gfx950.txt} $O/${P}_tune.txt
 SDMI_TUNE_FILE=$O/${P}_tune.txt timeout 1200 python tools/tune.py --rounds 72 --reps 4 --out $O/${P}_tune.txt --dump $O/${P}_tune_dump.txt > $O/${P}_tune.log 2>&1; el "tune all workloads exit $? : $(tail -1 $O/${P}_tune.log)"
 diff <(grep -v "^#" $O/${P}_tune_i.txt | cut -d" " -f1-10 | sort) <(grep -v "^#" $O/${P}_tune.txt | cut -d" " -f1-10 | sort) | grep -c "^>" | xargs echo "rows changed against pass I's table:"
 for r in 1 2 3; do
