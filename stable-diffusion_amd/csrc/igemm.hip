@@ -648,13 +648,13 @@ __device__ __forceinline__ TiledQuad tiled_quad(const IGemmParams& p, int q, int
 // wave's rows lie inside one sample: the statistics are combined per wave in LDS and leave as one atomic set per (wave, group).
 __global__ void __launch_bounds__(256) splitk_reduce_tiled_kernel(IGemmParams p, int nsplit) {
   __shared__ unsigned long long s_gn[2][4][32][GN_WORDS];        // [target][wave][group]
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NTB = blockDim.x;      // (256 threads, or 128: SDMI_REDUCE_BLOCK)
   const bool gn = p.gn_n > 0;
   if (gn) {
-    for (int i = tid; i < 2 * 4 * 32 * GN_WORDS; i += 256) (&s_gn[0][0][0][0])[i] = 0ull;
+    for (int i = tid; i < 2 * 4 * 32 * GN_WORDS; i += NTB) (&s_gn[0][0][0][0])[i] = 0ull;
     __syncthreads();
   }
-  const TiledQuad t = tiled_quad(p, blockIdx.x * 256 + tid, lane);
+  const TiledQuad t = tiled_quad(p, blockIdx.x * NTB + tid, lane);
   const int ntiles = ((p.M + p.slab_bm - 1) / p.slab_bm) * ((p.N + p.slab_bn - 1) / p.slab_bn);
   const size_t split_stride = (size_t)ntiles * (size_t)(p.slab_bm * p.slab_bn);
   const float* src = p.splitk_ws + t.off;
@@ -699,12 +699,13 @@ __global__ void __launch_bounds__(256) splitk_reduce_tiled_kernel(IGemmParams p,
     }
     __syncthreads();
     const int slot = blockIdx.x & (GN_SLOTS - 1);
-    for (int e = tid; e < p.gn_n * 4 * 32 * GN_WORDS; e += 256) {
+    for (int e = tid; e < p.gn_n * 4 * 32 * GN_WORDS; e += NTB) {
       const unsigned long long w = (&s_gn[0][0][0][0])[e];
       if (w == 0ull) continue;
       const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, w4 = (e / (GN_WORDS * 32)) % 4, tg = e / (GN_WORDS * 32 * 4);
       // the sample of that wave's 32-row slab: its first row (lane 0 of the wave would own it)
-      const TiledQuad t0 = tiled_quad(p, blockIdx.x * 256 + w4 * 64, 0);
+      if (w4 * 64 >= NTB) continue;
+      const TiledQuad t0 = tiled_quad(p, blockIdx.x * NTB + w4 * 64, 0);
       if (t0.m >= p.M) continue;
       const int b = t0.m / HW;
       atomicAdd((unsigned long long*)p.gn_acc[tg] + ((size_t)(b * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
@@ -834,7 +835,10 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     }
     if (p.gn_n > 0) SDMI_CHECK((p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
     ProfScope pst("splitk_reduce", 0.0, mn * 4.0 * (nsplit + 1), stream);
-    hipLaunchKernelGGL(splitk_reduce_tiled_kernel, dim3((unsigned)(quads / 256)), dim3(256), 0, stream, p, nsplit);
+    // threads per block: 256, or 128 where that still leaves fewer than two blocks per CU (SDMI_REDUCE_BLOCK: 0 auto, 128 / 256 forced; A/B)
+    const int rb_env = env_int("SDMI_REDUCE_BLOCK", 256);
+    const int rb = (rb_env == 128 || (rb_env == 0 && quads / 256 < 512)) ? 128 : 256;
+    hipLaunchKernelGGL(splitk_reduce_tiled_kernel, dim3((unsigned)(quads / rb)), dim3(rb), 0, stream, p, nsplit);
     SDMI_HIP_OK(hipGetLastError());
     pst.end();
     if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);
