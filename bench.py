@@ -480,9 +480,13 @@ def main():
                 if hbm:
                     h = hbm[0]
                     gbs = h['bytes'] / (h['ms'] * 1e-3) / 1e9
+                    # measured HBM bytes per launch of that class from the committed PMC pass (same source as roofline.traffic)
+                    t_hbm = offline_traffic(h['name']) if h['name'] in ('groupnorm', 'splitk_reduce', 'layernorm') else None
                     out['roofline_hbm'] = {'bound': 'hbm', 'kernel': h['name'], 'launches_per_unet_call': h['launches'],
                                            'avg_launch_ms': h['ms'] / h['launches'], 'achieved': gbs, 'peak': HBM_PEAK_GBS,
-                                           'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS, 'traffic': None}
+                                           'unit': 'GB/s', 'frac': gbs / HBM_PEAK_GBS,
+                                           'traffic': t_hbm['gbytes_per_launch'] * 1e9 if t_hbm else None,
+                                           'algorithmic_gbytes_per_launch': h['bytes'] / h['launches'] / 1e9}
             if not args.no_cpu_baseline and args.workload == 'txt2img512':     # the CPU comparator is quoted on the headline config
                 out['cpu_baseline'] = cpu_baseline()
         print(json.dumps(out))
