@@ -469,3 +469,64 @@ def test_reference_bytecode_bundle_builds_and_imports_sourceless(tmp_path):
             "assert u.__file__.endswith('.pyc'), u.__file__; print(u.instantiate_from_config.__name__)")
     r = subprocess.run([sys.executable, '-c', code, out], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0 and 'instantiate_from_config' in r.stdout, r.stderr[-800:]
+
+
+def test_register_order_slab_layout_model():
+    """The split-K slab layout of round 4 (csrc/igemm_dev.h igemm_epilogue: slab_tiled branch; csrc/igemm.hip tiled_quad + quad_transpose),
+    restated in Python: the GEMM side's (row, column) -> slab float index and the reduction side's thread -> (row, 4 columns) decode must
+    be inverse to each other for every tile geometry the launchers use -- a host-side guard for edits to either half."""
+    def gemm_index(m, n, BM, BN, WM, WN, tiles_n):
+        """float index inside one split's slab of accumulator element (m, n): MFMA 32x32 C layout, 16 bytes = 4 consecutive rows of a lane"""
+        WTM, WTN, NT = BM // WM, BN // WN, WM * WN * 64
+        TN = WTN // 32
+        tile_m, mm = divmod(m, BM); tile_n, nn = divmod(n, BN)
+        wm, mw = divmod(mm, WTM); wn, nw = divmod(nn, WTN)
+        i, r32 = divmod(mw, 32); j, l31 = divmod(nw, 32)
+        # row inside a 32x32 tile = (r & 3) + 8 * (r >> 2) + 4 * lg
+        e, lg, r4 = r32 & 3, (r32 >> 2) & 1, r32 >> 3
+        tid = (wm * WN + wn) * 64 + lg * 32 + l31
+        return (tile_m * tiles_n + tile_n) * BM * BN + ((i * TN + j) * 4 + r4) * (NT * 4) + tid * 4 + e
+
+    def reduce_decode(q, lane, BM, BN, WM, WN, tiles_n):
+        """splitk_reduce_tiled_kernel: thread q (slab quad index) owns, after the lane transpose, row m and columns n .. n + 3"""
+        WTM, WTN, NT = BM // WM, BN // WN, WM * WN * 64
+        TN = WTN // 32
+        qpt = BM * BN // 4
+        tile, rem = divmod(q, qpt)
+        blk, t_in = divmod(rem, NT)
+        assert t_in % 64 == lane
+        wave = t_in >> 6
+        ij, r4 = blk >> 2, blk & 3
+        i, j = divmod(ij, TN)
+        wm, wn = divmod(wave, WN)
+        tile_m, tile_n = divmod(tile, tiles_n)
+        l31, lg = lane & 31, lane >> 5
+        m = tile_m * BM + wm * WTM + i * 32 + 8 * r4 + 4 * lg + (l31 & 3)
+        n = tile_n * BN + wn * WTN + j * 32 + (l31 & ~3)
+        return m, n
+
+    geoms = [(64, 64, 2, 2), (128, 64, 2, 2), (128, 128, 2, 2), (256, 128, 4, 2), (64, 128, 2, 2), (128, 128, 4, 2), (128, 256, 2, 4),
+             (64, 256, 1, 4), (256, 64, 4, 1), (256, 64, 4, 2), (128, 64, 2, 2)]
+    for BM, BN, WM, WN in geoms:
+        tiles_m, tiles_n = 2, 3
+        M, N = tiles_m * BM, tiles_n * BN
+        owner = {}
+        nquads = tiles_m * tiles_n * BM * BN // 4
+        for q in range(0, nquads, 7):                       # a stride that visits every lane / wave / block position
+            lane = q % 64
+            # the slab quad thread q LOADS holds rows 8 r4 + 4 lg + e (e = 0..3) of column l31: its four floats
+            m, n = reduce_decode(q, lane, BM, BN, WM, WN, tiles_n)
+            # after the transpose it owns (m, n..n+3): those four elements must sit at element (m & 3) of the quads of the four lanes of its lane quad
+            for c in range(4):
+                idx = gemm_index(m, n + c, BM, BN, WM, WN, tiles_n)
+                src_q = idx // 4
+                assert idx % 4 == (m & 3)
+                assert src_q // 64 == q // 64 and (src_q % 64) // 4 == lane // 4 and (src_q % 64) % 4 == c, (BM, BN, q, c)
+            owner[(m, n)] = q
+        assert all(0 <= m < M and 0 <= n < N and n % 4 == 0 for m, n in owner)
+        # and the GEMM-side index is a bijection onto [0, M * N)
+        seen = set()
+        for m in range(0, M, 5):
+            for n in range(0, N, 3):
+                seen.add(gemm_index(m, n, BM, BN, WM, WN, tiles_n))
+        assert len(seen) == len(range(0, M, 5)) * len(range(0, N, 3)) and max(seen) < M * N
