@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 11
+#define SDMI_ABI_VERSION 12
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -240,8 +240,20 @@ typedef struct sdmi_igemm_desc {
    * ordinary one and pgn_out is untouched. */
   const float* pgn_gamma; const float* pgn_beta; float pgn_eps; int32_t pgn_silu;
   void* pgn_out; int32_t pgn_keep_f32; int32_t* pgn_applied;
+  /* optional (ABI 12; mode 0, ldo % 4 == 0): fp16(v - float(fp16(v))) beside out_f16 -- the low half of the split-fp16 operand a
+   * following split16 GEMM reads (the last FF-out of a SpatialTransformer feeds proj_out this way) */
+  void* out_lo;
 } sdmi_igemm_desc;
 int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
+/* GEGLU -> FF-out -> proj_out of a SpatialTransformer as ONE launch (ABI 12; csrc/rowchain.hip; ldm/modules/attention.py:58-64,214,
+ * 258-261): out = residual + proj_out(t + FF(norm3(t))) for C = 320 channels, a workgroup per 32 token rows.
+ * proj_out: the split-fp16 1x1 descriptor of the last GEMM (split16 = 1, c0 = N = C, w = sdmi_k_pack_split3, bias, residual, out_f32,
+ * optional out_f16 copy / gn_* statistics targets; B * Hout * Wout = M rows, Hout * Wout % 32 == 0) -- a0 / a1 are not read.
+ * ln_f16 [M][C] = fp16(gamma3 * t) and lnp [C / 32][M][2]: what the producer of t stored (f16_scale / lnp_out above);
+ * csd: the GEGLU projection's LayerNorm-fold column terms (sdmi_k_ln_fold_prep over the packed weights, bias inside d) regrouped per
+ * hidden chunk of C: [4][cs of 2C packed columns | d of the same 2C]; wgg [8C][C], wff2 [C][4C] fp16, bff2 [C], t [M][C] fp32. */
+int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const float* lnp, float ln_eps, const float* csd,
+                   const void* wgg_f16, const void* wff2_f16, const float* bff2, const float* t, void* stream);
 /* cs[n] = sum_k gamma[k] * w[n][k], d[n] = sum_k beta[k] * w[n][k] (+ bias[n]) over the PACKED fp16 weights w [N][ldw]
  * (first K columns of a row): the column terms of a GEMM that folds LayerNorm(gamma, beta) of its input rows */
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,

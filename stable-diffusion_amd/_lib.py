@@ -46,7 +46,8 @@ class IGemmDesc(C.Structure):
                 ('f16_scale', c_ptr), ('lnp_out', c_ptr), ('lnf_part', c_ptr), ('lnf_npart', C.c_int32),
                 ('lnf_eps', C.c_float), ('lnf_cs', c_ptr), ('lnf_d', c_ptr),
                 ('pgn_gamma', c_ptr), ('pgn_beta', c_ptr), ('pgn_eps', C.c_float), ('pgn_silu', C.c_int32),
-                ('pgn_out', c_ptr), ('pgn_keep_f32', C.c_int32), ('pgn_applied', C.POINTER(C.c_int32))]
+                ('pgn_out', c_ptr), ('pgn_keep_f32', C.c_int32), ('pgn_applied', C.POINTER(C.c_int32)),
+                ('out_lo', c_ptr)]
 
 
 _SIGS = {
@@ -91,6 +92,7 @@ _SIGS = {
     'sdmi_clip_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int]),
     'sdmi_clip_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_igemm': (C.c_int, [C.POINTER(IGemmDesc), c_ptr]),
+    'sdmi_k_ff_tail': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sdmi_k_attention_causal': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                           c_ptr]),
     'sdmi_k_pointwise_nchw': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, c_ptr]),
@@ -149,7 +151,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 11:
+        if lib.sdmi_abi_version() != 12:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 EXTRA = os.environ.get('SDMI_CXXFLAGS', '').split()
 LIB = os.path.join(HERE, os.environ.get('SDMI_LIB_OUT', 'libsdmi.so'))
 OBJ = os.path.join(HERE, 'build' if os.path.basename(LIB) == 'libsdmi.so' else 'build_' + os.path.splitext(os.path.basename(LIB))[0])
-SOURCES = ['igemm.hip', 'conv3halo.hip', 'gemm_split16.hip', 'igemm5.hip', 'range.hip', 'attn.hip', 'attn_ctx.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
+SOURCES = ['igemm.hip', 'conv3halo.hip', 'gemm_split16.hip', 'igemm5.hip', 'rowchain.hip', 'range.hip', 'attn.hip', 'attn_ctx.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable']
 
@@ -50,6 +50,7 @@ def build(force=False, verbose=True):
     if not force and is_current():
         return LIB
     hipcc = _hipcc()
+    stamp_now = _stamp()       # of the sources as they are NOW: an edit made while the compilers run must leave the library stale
 
     inc_dirs = (CSRC, os.path.join(os.path.dirname(HERE), 'include'))
 
@@ -98,7 +99,7 @@ def build(force=False, verbose=True):
     if r.returncode != 0:
         raise RuntimeError(f'link failed:\n{r.stdout}\n{r.stderr}')
     with open(stamp_file, 'w') as f:
-        f.write(_stamp())
+        f.write(stamp_now)
     if verbose:
         print(f'built {LIB} ({os.path.getsize(LIB) / 1e6:.1f} MB)')
     return LIB

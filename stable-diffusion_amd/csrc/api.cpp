@@ -237,9 +237,7 @@ int sdmi_k_attention_causal(const void* q, const void* k, const void* vt, void* 
 }
 
 // ---- kernel-level entry points ------------------------------------------------------------------------
-int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
-  SDMI_CHECK(d, "null descriptor");
-  IGemmParams p;
+static int igemm_params_of(const sdmi_igemm_desc* d, IGemmParams& p) {
   p.a0 = (const f16*)d->a0; p.a1 = (const f16*)d->a1; p.a2 = (const f16*)d->a2;
   p.c0 = d->c0; p.c1 = d->c1; p.c2 = d->c2; p.lda0 = d->lda0; p.lda1 = d->lda1; p.lda2 = d->lda2;
   p.B = d->B; p.Hin = d->Hin; p.Win = d->Win; p.Hout = d->Hout; p.Wout = d->Wout;
@@ -260,9 +258,25 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
   p.lnf_part = d->lnf_part; p.lnf_npart = d->lnf_npart; p.lnf_eps = d->lnf_eps; p.lnf_cs = d->lnf_cs; p.lnf_d = d->lnf_d;
   p.pgn_gamma = d->pgn_gamma; p.pgn_beta = d->pgn_beta; p.pgn_eps = d->pgn_eps; p.pgn_silu = d->pgn_silu;
   p.pgn_out = (f16*)d->pgn_out; p.pgn_keep_f32 = d->pgn_keep_f32; p.pgn_applied = d->pgn_applied;
-  if (zero_page(&p.zero_page)) return -1;
+  p.out_lo = (f16*)d->out_lo;
+  return zero_page(&p.zero_page);
+}
+int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream) {
+  SDMI_CHECK(d, "null descriptor");
+  IGemmParams p;
+  if (igemm_params_of(d, p)) return -1;
   IGemmTune t; t.tile = d->tile; t.dma = d->dma;
   return launch_igemm(p, t, (hipStream_t)stream);
+}
+int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const float* lnp, float ln_eps, const float* csd,
+                   const void* wgg_f16, const void* wff2_f16, const float* bff2, const float* t, void* stream) {
+  SDMI_CHECK(proj_out, "null descriptor");
+  FfTailParams q;
+  if (igemm_params_of(proj_out, q.epi)) return -1;
+  SDMI_CHECK(proj_out->split16 && proj_out->ksize == 1, "ff_tail: the proj_out descriptor is a split-fp16 1x1 (w = sdmi_k_pack_split3)");
+  q.ln = (const f16*)ln_f16; q.lnp = lnp; q.ln_eps = ln_eps; q.csd = csd; q.wgg = (const f16*)wgg_f16; q.wff2 = (const f16*)wff2_f16;
+  q.bff2 = bff2; q.t = t; q.wpo = (const f16*)proj_out->w;
+  return launch_ff_tail(q, (hipStream_t)stream);
 }
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,
                         float* cs, float* d, void* stream) {

@@ -785,8 +785,16 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
   static const int use_v1 = getenv("SDMI_ATTN_V1") ? atoi(getenv("SDMI_ATTN_V1")) : 0;     // A/B: the register-staged kernel
   constexpr int DNS = (D > 128) ? 3 : 4;                        // LDS-DMA ring depth (D = 160: 3 x 44 KB)
   if (!use_v1 && !p.causal && (p.nkv * D) % 8 == 0) {
-    static const int abl = getenv("SDMI_ATTN_ABL") ? atoi(getenv("SDMI_ATTN_ABL")) : 0;     // timing-only, see the kernel
+    // timing-only ablations (WRONG results: each removes one ingredient of the loop, tools/attn_ablate.py) exist only in a build with
+    // -DSDMI_ABLATE (SDMI_CXXFLAGS=-DSDMI_ABLATE SDMI_LIB_OUT=libsdmi_ablate.so python stable-diffusion_amd/build.py): no environment
+    // variable can make the product library compute something else
+#ifdef SDMI_ABLATE
+    static const int abl = getenv("SDMI_ATTN_ABL") ? atoi(getenv("SDMI_ATTN_ABL")) : 0;
+#else
+    constexpr int abl = 0;
+#endif
     if (D == 40 && nw == 8 && abl) {
+#ifdef SDMI_ABLATE
       if constexpr (D == 40) {
         switch (abl) {
           case 1: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 1>), grid, dim3(512), 0, stream, p); break;
@@ -797,6 +805,7 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
           default: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 6>), grid, dim3(512), 0, stream, p); break;
         }
       }
+#endif
     } else if (nw == 8 && p.pingpong && DNS >= 4) {
       if constexpr (DNS >= 4) hipLaunchKernelGGL((attn_pp_kernel<D, DNS>), grid, dim3(512), 0, stream, p);
     } else if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);

@@ -101,7 +101,10 @@ enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 // sc1 is; a 16-byte sc1 store costs what a plain one does, narrower ones are one fabric write each).  Same values, same addresses:
 // bit-identical.  Same-box A/B (profiles/wt_stores_r04.txt): -0.03 ms per UNet call (-0.5 %), first-stage decode unchanged;
 // -DSDMI_WT_STORES=2 (the 8-byte fp16 stores as well) measured the same as 1, -DSDMI_WT_STORES=0 = plain stores.
-// base = wave-uniform tensor base, off = element offset (byte offset < 2^31: every tensor here is far below 2 GB).
+// base = wave-uniform tensor base, off = element offset.  The buffer instruction takes a 32-bit byte offset checked against 2^31
+// records: a lane whose byte offset does not fit (outputs beyond 2 GB: first-stage decodes at 768 x 768 with 4+ images, 1024 x 1024
+// with 3+) takes the plain 64-bit store instead -- same value, same address; a store past 2^31 would otherwise be dropped by the range
+// check and one past 2^32 would wrap onto an earlier sample.
 #ifndef SDMI_WT_STORES
 #define SDMI_WT_STORES 1
 #endif
@@ -109,12 +112,20 @@ enum EpiMode { EPI_PLAIN = 0, EPI_GEGLU = 1, EPI_HEADS = 2 };
 typedef unsigned sdmi_u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned sdmi_u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ void sdmi_st_wt16(const void* base, size_t byte_off, f32x4 v) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sdmi_u32x4, v), r, (int)byte_off, 0, 16);
+  if (__builtin_expect(byte_off < (size_t)0x80000000u - 16, 1)) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(sdmi_u32x4, v), r, (int)byte_off, 0, 16);
+  } else {
+    *(f32x4*)((char*)base + byte_off) = v;
+  }
 }
 __device__ __forceinline__ void sdmi_st_wt8(const void* base, size_t byte_off, f16x4 v) {
-  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000, 0x00020000);
-  __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sdmi_u32x2, v), r, (int)byte_off, 0, 16);
+  if (__builtin_expect(byte_off < (size_t)0x80000000u - 16, 1)) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x80000000, 0x00020000);
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(sdmi_u32x2, v), r, (int)byte_off, 0, 16);
+  } else {
+    *(f16x4*)((char*)base + byte_off) = v;
+  }
 }
 #define SDMI_ST_F32X4(base, off, val) sdmi_st_wt16((base), (size_t)(off) * 4, (val))
 #if SDMI_WT_STORES >= 2
@@ -267,6 +278,28 @@ int tune_end(const char* path, int* n_keys);
 int tune_dump(std::string* out);
 // out = sum_s slab[s] + bias + rowvec[batch] + residual (fixed order); uses M, N, Hout*Wout, splitk_ws, out_f32/out_f16
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
+
+// Row-strip chain (rowchain.hip): GEGLU -> FF-out -> proj_out of a SpatialTransformer as ONE launch (attention.py:58-64,214,258-261).
+// A workgroup owns 32 token rows for the whole chain; the weights stream through one LDS-DMA ring.  `epi` is the descriptor of the
+// proj_out GEMM (M, N = K = C, B, Hout * Wout = rows per sample, bias, residual = the SpatialTransformer's input, out_f32 / ldo,
+// optional fp16 copy and GroupNorm-statistics targets); the operand pointers of that descriptor are not read.
+struct FfTailParams {
+  const f16* ln = nullptr;        // [M][C] fp16(gamma3 * t): the LayerNorm-folded GEGLU operand its producer stored (IGemmParams::f16_scale)
+  const float* lnp = nullptr;     // [C / 32][M][2] row partials of t (IGemmParams::lnp_out)
+  float ln_eps = 1e-5f;
+  const float* csd = nullptr;     // LayerNorm-fold column terms of the packed GEGLU columns, per hidden chunk of C: [4][cs 2C | d 2C]
+  const f16* wgg = nullptr;       // [8C][C] packed GEGLU weights (value32 | gate32 interleave)
+  const f16* wff2 = nullptr;      // [C][4C]
+  const float* bff2 = nullptr;    // [C]
+  const float* t = nullptr;       // [M][C] fp32 token stream (residual of FF-out)
+  const f16* wpo = nullptr;       // [C][3C] split-fp16 proj_out weights [hi | hi | lo]
+#ifdef SDMI_RC_TIMING
+  long long* dbg = nullptr;       // timing build only: [workgroups][128] s_memtime stamps
+#endif
+  IGemmParams epi;
+};
+bool ff_tail_supported(int C, int M, int rows_per_sample);
+int launch_ff_tail(const FfTailParams& p, hipStream_t stream);
 
 // Flash attention over per-head layouts produced by EPI_HEADS
 struct AttnParams {

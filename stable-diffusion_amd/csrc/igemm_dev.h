@@ -701,6 +701,11 @@ static bool slab_tiled_ok(const IGemmParams& p, int bm, int bn, int nsplit) {
   if (!on || nsplit <= 1 || splitk_fusable(p, bm, bn) || p.mode == EPI_GEGLU || p.N % 4) return false;
   if ((bm & (bm - 1)) || (bn & (bn - 1))) return false;
   if (p.mode == EPI_PLAIN && p.gn_n > 0 && reduce_rows_per_block(p) != 32) return false;
+  // the tiled branch of igemm_epilogue returns before the LayerNorm-fold correction, and splitk_reduce_tiled_kernel knows neither
+  // f16_scale nor lnp_out: those launches are pinned to split 1 by launch_igemm -- keep the dependency here as well
+  if (p.lnf_part || p.lnp_out || p.f16_scale) return false;
+  // whole padded tiles must fit the workspace; a caller that sized it as splitk * M * N (the row-major contract) keeps that layout
+  if ((int64_t)nsplit * cdiv(p.M, bm) * bm * cdiv(p.N, bn) * bn > p.splitk_ws_floats) return false;
   return true;
 }
 static void slab_layout(IGemmParams& q, int bm, int bn, int wm, int wn, int nsplit) {

@@ -361,6 +361,13 @@ int UNet::finalize() {
             return -1;
           if (launch_ln_fold_prep(w_[i], n_[i], C, C, T.ln[2 * i], T.ln[2 * i + 1], b_[i], T.lnf[2 * i], T.lnf[2 * i + 1], nullptr)) return -1;
         }
+        if (ff_tail_supported(C, 32, 32)) {            // (geometry only: rows are checked per call)
+          if (dev_alloc((void**)&T.lnf_csd, (size_t)16 * C * sizeof(float))) return -1;
+          for (int h = 0; h < 4; ++h) {                 // (default stream, behind the prep kernels above)
+            SDMI_HIP_OK(hipMemcpyAsync(T.lnf_csd + (size_t)h * 4 * C, T.lnf[4] + (size_t)h * 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+            SDMI_HIP_OK(hipMemcpyAsync(T.lnf_csd + (size_t)h * 4 * C + 2 * C, T.lnf[5] + (size_t)h * 2 * C, (size_t)2 * C * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+          }
+        }
       }
       return 0;
     };
@@ -452,6 +459,7 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
 struct Fwd : FwdBase {
   UNet* u; int Lctx;
   bool ln_fold_on = false;      // this call folds LayerNorms into their consuming GEMMs (UNet::ln_fold_; read per call: A/B knobs)
+  bool ff_tail_on = false;      // ... and runs SpatialTransformer tails as row-strip chain launches (UNet::ff_tail_; SDMI_FF_TAIL, read per call)
   // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
   bool fuse_ctx_q = false;
@@ -610,6 +618,10 @@ struct Fwd : FwdBase {
       gemm(p);
     }
     const int depth = (int)L.tb.size();
+    // the tail of the SpatialTransformer (GEGLU -> FF-out -> proj_out) as one row-strip chain launch: last (= only) transformer block,
+    // LayerNorm fold on, split-fp16 proj_out, C = 320 (UNet::ff_tail_)
+    const bool chain_ff = ff_tail_on && fold_ln && precise_1x1 && depth == 1 && L.tb[0].lnf_csd != nullptr && ff_tail_supported(C, M, N) &&
+                          dense1x1(nullptr, nullptr, M, C, L.w16[1], C, N).split16;
     for (int d = 0; d < depth; ++d) {
       TBlock& T = L.tb[d];
       // x = attn1(norm1(x)) + x                                   attention.py:212
@@ -656,6 +668,7 @@ struct Fwd : FwdBase {
         gemm(p);
       }
       // x = ff(norm3(x)) + x                                       attention.py:214
+      if (chain_ff) break;                   // (depth 1: GEGLU, FF-out and proj_out are the chain launch below)
       {
         IGemmParams p = dense(ln, M, C, T.wgg, 8 * C, N);
         p.mode = EPI_GEGLU; p.bias = T.bgg; p.out_f16 = gg; p.ldo = 4 * C; p.splitk = 1;
@@ -682,7 +695,16 @@ struct Fwd : FwdBase {
       p.bias = L.f32[3]; p.residual = x.p; p.ldr = C; p.out_f32 = out.p; p.ldo = C;
       attach_gn_targets(p, out);
       attach_f16_copy(p, out);
-      gemm(p);
+      if (chain_ff) {
+        // out = x + proj_out(t + FF(norm3(t))): one row-strip chain launch (rowchain.hip); `ln` / `lnp` are what attn2's out-projection stored
+        TBlock& T = L.tb[0];
+        FfTailParams q;
+        q.ln = ln; q.lnp = lnp; q.ln_eps = 1e-5f; q.csd = T.lnf_csd; q.wgg = T.wgg; q.wff2 = T.wff2; q.bff2 = T.bff2; q.t = t; q.wpo = L.w16[1];
+        q.epi = p;
+        if (!dry && !rc) ok(launch_ff_tail(q, s));
+      } else {
+        gemm(p);
+      }
     }
     scratch.off = mark;
     return out;
@@ -834,6 +856,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     // (both knobs are read per call -- the tests flip them between two forwards; the row statistics ride on the 16-byte epilogue)
     const char* e_fold = getenv("SDMI_LN_FOLD"); const char* e_vec = getenv("SDMI_EPI_VEC");
     f.ln_fold_on = (e_fold ? atoi(e_fold) != 0 : ln_fold_) && !(e_vec && atoi(e_vec) == 0);
+    const char* e_ff = getenv("SDMI_FF_TAIL");
+    f.ff_tail_on = e_ff ? atoi(e_ff) != 0 : ff_tail_;
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);

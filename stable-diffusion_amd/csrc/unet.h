@@ -247,6 +247,9 @@ struct TBlock {   // BasicTransformerBlock (ldm/modules/attention.py:196-215)
   // LayerNorm folded into the consuming GEMM (IGemmParams::lnf_cs / lnf_d; computed by finalize() from the packed weights):
   // {cs, d} of attn1 q|k|v with norm1, attn2 to_q with norm2, the GEGLU projection with norm3 (packed column order, bias inside d)
   float* lnf[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  // the GEGLU projection's {cs, d} regrouped per hidden chunk of C for the row-strip chain (rowchain.hip, FfTailParams::csd):
+  // [4][cs of 2C packed columns | d of the same 2C]; filled by finalize() where the chain geometry exists (C = 320)
+  float* lnf_csd = nullptr;
 };
 
 struct Layer {
@@ -318,6 +321,9 @@ class UNet {
   // GEMM is not split (>= ln_fold_min_rows_ token rows; the fold pins its producers to split 1): no LayerNorm launch, one fp32 read of the token stream less per site.
   // SDMI_LN_FOLD=0 restores the launches (A/B); SDMI_LN_FOLD_MIN_ROWS moves the threshold.
   bool ln_fold_ = true; int ln_fold_min_rows_ = 512;
+  // SpatialTransformer tails (GEGLU -> FF-out -> proj_out) as one row-strip chain launch where the geometry fits (the 64 x 64 level of
+  // SD v1: C = 320); rides on the LayerNorm fold.  SDMI_FF_TAIL=0 restores the three launches (bit-identical outputs; A/B).
+  bool ff_tail_ = true;
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
   std::vector<Layer> middle_;

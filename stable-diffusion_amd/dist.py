@@ -25,10 +25,35 @@ def init_from_env(backend=None):
         os.environ.setdefault('MASTER_PORT', '29500')
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+        kw = {}
         if backend == 'nccl':
+            # one process per GPU: bind the device BEFORE the communicator exists and tell the process group which one it is --
+            # without device_id RCCL "guesses the device from the global rank" (its own warning), which is wrong as soon as ranks
+            # and local devices are numbered differently
+            n_dev = torch.cuda.device_count()
+            if not 0 <= local_rank < n_dev:
+                raise RuntimeError(f'LOCAL_RANK={local_rank} but this process sees {n_dev} GPU(s): launch one process per visible GPU')
             torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            kw['device_id'] = torch.device('cuda', local_rank)
+        try:
+            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+        except TypeError:            # (a torch without the device_id keyword)
+            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if backend == 'nccl' and torch.cuda.current_device() != local_rank:
+            raise RuntimeError(f'rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}')
+        if dist.get_world_size() != world or dist.get_rank() != rank:
+            raise RuntimeError(f'process group says rank {dist.get_rank()} / {dist.get_world_size()}, the environment {rank} / {world}')
     return rank, world, local_rank
+
+
+def ranks_seen(device=None):
+    """How many ranks actually took part: an all_reduce(SUM) of ones over the live communicator (what a SCALE record can be checked
+    against, next to RCCL's own `nranks`); 1 without a process group."""
+    if not dist.is_initialized():
+        return 1
+    t = torch.ones(1, dtype=torch.int64, device=device if device is not None else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def shard(items, rank, world):

@@ -43,7 +43,7 @@ def cast_f16(x, want_lo=False):
 
 def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a2=None, bias=None, rowvec=None,
           residual=None, out_f32=None, out_f16=None, ldo=None, mode=0, splitk=1, tile=-1, dma=-1, heads=None, fused_splitk=True,
-          asym_pad=0, gn=None, split16=False, f16_scale=None, lnp_out=None, lnf=None, pgn=None):
+          asym_pad=0, gn=None, split16=False, f16_scale=None, lnp_out=None, lnf=None, pgn=None, out_lo=None):
     """a0/a1: fp16 [B*Hin*Win, C] ; w: fp16 [N, K].
     LayerNorm fold: producer f16_scale (gamma [N]) + lnp_out ([N/32, M, 2] fp32); consumer lnf = (partials, eps, cs, d)."""
     d = _lib.IGemmDesc()
@@ -70,6 +70,7 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
     d.asym_pad = asym_pad
     d.split16 = 1 if split16 else 0      # a0 = hi, a1 = lo, w = pack_split3 ([N][3 c0])
     d.f16_scale = _lib.ptr(f16_scale); d.lnp_out = _lib.ptr(lnp_out)
+    d.out_lo = _lib.ptr(out_lo)
     if lnf is not None:
         part, eps, cs, dn = lnf
         d.lnf_part = part.data_ptr(); d.lnf_npart = part.shape[0]; d.lnf_eps = float(eps)
@@ -93,6 +94,23 @@ def igemm(a0, w, N, B, Hin, Win, Hout, Wout, ksize=1, stride=1, up=0, a1=None, a
             d.splitk_cnt = cnt.data_ptr(); d.splitk_cnt_ints = cnt.numel()
     _lib.check(_lib.load().sdmi_k_igemm(C.byref(d), _s()))
     return int(applied.value)
+
+
+def ff_tail(ln16, part, eps, csd, wgg, wff2, bff2, t, wpo3, bpo, x_in, out_f32, B, ntok, out_f16=None, gn=None):
+    """GEGLU -> FF-out -> proj_out as one launch (sdmi_k_ff_tail): out = x_in + proj_out(t + FF(norm3(t))).
+    ln16 [M, C] fp16(gamma3 * t), part [C/32, M, 2]; csd [4, 2 * 2C] per-chunk {cs | d}; wpo3 = pack_split3(w_proj_out)."""
+    C_ = ln16.shape[1]
+    d = _lib.IGemmDesc()
+    d.c0 = C_; d.lda0 = C_; d.B, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride = B, ntok, 1, ntok, 1, 1, 1
+    d.w = wpo3.data_ptr(); d.N = C_; d.mode = 0; d.split16 = 1; d.splitk = 1; d.tile = -1; d.dma = -1
+    d.bias = _lib.ptr(bpo); d.residual = x_in.data_ptr(); d.ldr = x_in.stride(0)
+    d.out_f32 = out_f32.data_ptr(); d.out_f16 = _lib.ptr(out_f16); d.ldo = out_f32.stride(0)
+    if gn:
+        d.gn_n = len(gn)
+        for i, (acc, cpg, cbase) in enumerate(gn):
+            d.gn_acc[i] = acc.data_ptr(); d.gn_cpg[i] = cpg; d.gn_cbase[i] = cbase
+    _lib.check(_lib.load().sdmi_k_ff_tail(C.byref(d), ln16.data_ptr(), part.data_ptr(), float(eps), csd.data_ptr(), wgg.data_ptr(),
+                                          wff2.data_ptr(), bff2.data_ptr(), t.data_ptr(), _s()))
 
 
 _CNT = {}

@@ -28,6 +28,7 @@ def _worker(rank, world, port, n_total, q):
     full = sd_dist.gather_latents(local, n_total, r, w)
     ok = full.shape == (n_total, 4, 8, 8) and all(float(full[i].mean()) == float(i) for i in range(n_total))
     mx = sd_dist.max_over_ranks(10.0 + rank, torch.device('cpu'))
+    ok = ok and sd_dist.ranks_seen(torch.device('cpu')) == world        # what bench.py reports as `ranks_seen`
     q.put((rank, bool(ok), mx))
     dist.destroy_process_group()
 

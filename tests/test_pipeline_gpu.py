@@ -18,8 +18,10 @@ from oracle.weights import make_state_dict  # noqa: E402
 
 # Budget: injecting the measured per-stage errors (eps rms 2e-4 / max 1e-3 per UNet call, context rms 6e-4) into the oracle
 # pipeline moves the final latent by ~2.4e-2 (|z| max ~18 with these random weights at scale 7.5) and the image by 1.5e-3.
-IMG_TOL = 6e-3        # on the [0, 1] image: 1.5 8-bit levels
-LAT_TOL = 6e-2        # on the final latent: 3.3e-3 of its range
+# Tolerances = 2x the errors measured on MI355X (round 4 / round 5 GPU logs; the per-call error does not compound over more steps here:
+# the sampler contracts towards x0), per (sampler, steps): {image on [0, 1], final latent (|z| max ~18)}.
+#   measured  plms S=5: 6.0e-4 ... 7.9e-4 / 7.6e-3     ddim S=5: 9.2e-4 ... 1.2e-3 / 1.3e-2
+TOLS = {('plms', 5): (2.0e-3, 1.6e-2), ('ddim', 5): (2.5e-3, 2.6e-2), ('plms', 20): (2.5e-3, 2.6e-2), ('ddim', 20): (2.5e-3, 2.6e-2)}
 
 
 def _text_config(cfg):
@@ -27,7 +29,7 @@ def _text_config(cfg):
                 num_hidden_layers=cfg.num_layers, num_attention_heads=cfg.num_heads, max_position_embeddings=cfg.max_positions)
 
 
-@pytest.mark.parametrize('sampler_name,S', [('plms', 5), ('ddim', 5)])
+@pytest.mark.parametrize('sampler_name,S', [('plms', 5), ('ddim', 5), ('plms', 20), ('ddim', 20)])
 def test_txt2img_pipeline_matches_oracle_pipeline(sampler_name, S):
     from stable_diffusion_amd import (AutoencoderKLHIP, DDIMSamplerHIP, FrozenCLIPEmbedderHIP, LatentDiffusionHIP,
                                       PLMSSamplerHIP, UNetModelHIP)
@@ -75,4 +77,5 @@ def test_txt2img_pipeline_matches_oracle_pipeline(sampler_name, S):
           f'image err {e_img:.3e} on [0,1] (mean {img_ref.mean():.3f}, frac clamped '
           f'{((img_ref == 0) | (img_ref == 1)).float().mean():.3f})', flush=True)
     assert img_h.shape == (1, 3, h * vae.factor, w * vae.factor) and torch.isfinite(img_h).all()
-    assert e_z <= LAT_TOL and e_img <= IMG_TOL
+    IMG_TOL, LAT_TOL = TOLS[(sampler_name, S)]
+    assert e_z <= LAT_TOL and e_img <= IMG_TOL, (e_z, LAT_TOL, e_img, IMG_TOL)

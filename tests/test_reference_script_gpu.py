@@ -29,6 +29,23 @@ BUNDLE = os.path.join(ROOT, 'oracle', '_ref', 'refbundle')
 pytestmark = pytest.mark.gpu
 
 
+def _bundle_usable():
+    """.pyc files are bound to the interpreter minor version that compiled them (MANIFEST.json records it): a different one would die
+    with 'bad magic number' instead of skipping"""
+    import json
+    man = os.path.join(BUNDLE, 'MANIFEST.json')
+    if not os.path.isdir(os.path.join(BUNDLE, 'ldm')) or not os.path.exists(man):
+        return False
+    try:
+        py = str(json.load(open(man)).get('python', ''))
+    except Exception:
+        return False
+    return py.split('.')[:2] == [str(sys.version_info[0]), str(sys.version_info[1])]
+
+
+NO_BUNDLE = 'no reference bytecode bundle for this interpreter (oracle/build_ref_bundle.py needs /root/reference at build time)'
+
+
 def _run(script, extra, outdir):
     cmd = [sys.executable, os.path.join(ROOT, 'tools', 'run_reference_script.py'), '--reference', '/nonexistent-on-purpose',
            '--hip', '--offline-stubs', script, '--', '--ckpt', 'synthetic', '--n_samples', '1', '--n_iter', '1',
@@ -45,8 +62,7 @@ def _calls(log):
     return tuple(int(g) for g in m.groups())
 
 
-@pytest.mark.skipif(not os.path.isdir(os.path.join(BUNDLE, 'ldm')),
-                    reason='no reference bytecode bundle (oracle/build_ref_bundle.py needs /root/reference at build time)')
+@pytest.mark.skipif(not _bundle_usable(), reason=NO_BUNDLE)
 def test_unmodified_txt2img_script_drives_the_hip_path(tmp_path):
     from PIL import Image
     out = tmp_path / 'txt2img'
@@ -60,8 +76,7 @@ def test_unmodified_txt2img_script_drives_the_hip_path(tmp_path):
     assert os.path.exists(out / 'grid-0000.png')
 
 
-@pytest.mark.skipif(not os.path.isdir(os.path.join(BUNDLE, 'ldm')),
-                    reason='no reference bytecode bundle (oracle/build_ref_bundle.py needs /root/reference at build time)')
+@pytest.mark.skipif(not _bundle_usable(), reason=NO_BUNDLE)
 def test_unmodified_img2img_script_drives_the_hip_path(tmp_path):
     from PIL import Image
     rng = np.random.default_rng(3)

@@ -85,29 +85,37 @@ def test_parity_headroom_report():
 def test_parity_does_not_depend_on_the_tuning_table():
     """The summation order of every GEMM depends on the committed (tile, split-K) table; a re-tune must not be what keeps
     the path under the bar.  Fresh process with SDMI_TUNE_DISABLE=1 (heuristic tiles and splits everywhere): the SD-v1
-    16x16 golden still has to hold, and the two builds' eps agree to the operand-rounding noise."""
+    goldens whose shapes the table re-decides most (16x16, the 32x32 concat blocks, the 64x64 bench workload, CFG batch 6)
+    still have to hold."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cases = ['sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64', 'sdv1_b6_16x16']
     code = (
         "import os, sys, numpy as np, torch\n"
         f"sys.path.insert(0, {root!r}); sys.path.insert(0, os.path.join({root!r}, 'tests'))\n"
         "from oracle.plan import SD_V1\n"
         "from oracle.weights import make_inputs, make_state_dict\n"
         "from stable_diffusion_amd import UNetModelHIP\n"
-        "z = np.load(os.path.join(sys.argv[1], 'unet_sdv1_16x16.npz'))\n"
-        "kw = SD_V1.ref_kwargs(); m = UNetModelHIP(**kw); m.load_state_dict(make_state_dict(SD_V1, int(z['weight_seed'])), strict=True)\n"
-        "m = m.cuda().eval()\n"
-        "x, t, ctx = make_inputs(SD_V1, 2, 16, 16, seed=int(z['input_seed']), ctx_len=77, timesteps=tuple(int(v) for v in z['t']))\n"
-        "eps = m(x.cuda(), t.cuda(), context=ctx.cuda()).float().cpu()\n"
-        "print('ERR', float((eps - torch.from_numpy(z['eps'])).abs().max()))\n")
+        "m = None\n"
+        "for case in sys.argv[2:]:\n"
+        "    z = np.load(os.path.join(sys.argv[1], f'unet_{case}.npz'))\n"
+        "    if m is None:\n"
+        "        kw = SD_V1.ref_kwargs(); m = UNetModelHIP(**kw); m.load_state_dict(make_state_dict(SD_V1, int(z['weight_seed'])), strict=True)\n"
+        "        m = m.cuda().eval()\n"
+        "    x, t, ctx = make_inputs(SD_V1, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']), ctx_len=int(z['ctx_len']),\n"
+        "                            timesteps=tuple(int(v) for v in z['t']))\n"
+        "    eps = m(x.cuda(), t.cuda(), context=ctx.cuda()).float().cpu()\n"
+        "    print('ERR', case, float((eps - torch.from_numpy(z['eps'])).abs().max()))\n")
     env = dict(os.environ, SDMI_TUNE_DISABLE='1')
     gd = os.path.join(root, 'tests', 'golden')
-    r = subprocess.run([sys.executable, '-c', code, gd], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, '-c', code, gd] + cases, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-2000:]
-    err = float([l for l in r.stdout.splitlines() if l.startswith('ERR')][-1].split()[1])
-    print(f'[unet sdv1_16x16, SDMI_TUNE_DISABLE=1] max-abs {err:.3e} (table: {_measured.get("sdv1_16x16", float("nan")):.3e})', flush=True)
-    assert err <= TOL
+    errs = {l.split()[1]: float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith('ERR')}
+    assert sorted(errs) == sorted(cases), r.stdout[-1000:]
+    for case in cases:
+        print(f'[unet {case}, SDMI_TUNE_DISABLE=1] max-abs {errs[case]:.3e} (table: {_measured.get(case, float("nan")):.3e})', flush=True)
+    assert max(errs.values()) <= TOL, errs
 
 
 @pytest.mark.parametrize('case', ['tiny_16x16', 'sdv1_16x16'])

@@ -304,6 +304,15 @@ def main():
         # a GPU box: no reference checkout, but the bytecode bundle oracle/build_ref_bundle.py compiled from it travelled with the repo
         print(f'run_reference_script: no reference checkout at {ref}; using the bytecode bundle {BUNDLE}', file=sys.stderr)
         ref = BUNDLE
+        try:
+            import json
+            built_for = str(json.load(open(os.path.join(BUNDLE, 'MANIFEST.json'))).get('python', ''))
+        except Exception:
+            built_for = ''
+        here = f'{sys.version_info[0]}.{sys.version_info[1]}'
+        if built_for and built_for.split('.')[:2] != here.split('.'):
+            raise SystemExit(f'the bytecode bundle was compiled by Python {built_for}, this is Python {here}: rebuild it '
+                             '(python oracle/build_ref_bundle.py) with this interpreter')
     assert os.path.isdir(os.path.join(ref, 'ldm')), f'reference checkout not found at {ref} (and no bundle at {BUNDLE})'
     sys.path.insert(0, ref)
     have_gpu = torch.cuda.is_available()
