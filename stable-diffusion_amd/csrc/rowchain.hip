@@ -10,45 +10,74 @@
 //
 // Design ("row-strip chains"): a workgroup OWNS 32 token rows for the whole chain -- 8192 / 32 = 256
 // workgroups = one per CU.  Every operand that is indexed by rows stays on the CU: the A operand of each GEMM is a 32 x K fp16
-// strip in LDS (the LayerNorm-folded rows, then the GEGLU output chunk, then the split-fp16 halves of the FF output), the fp32
-// token stream of the strip lives in registers in the MFMA accumulator layout.  What streams is the WEIGHTS, all 2.8 MB of
-// them, through one LDS-DMA ring that never drains between GEMMs: the unit is 160 weight rows x 64 k (20 KB), five waves side by
-// side own one 32 x 32 MFMA tile of it each, and the schedule of units is one flat sequence
-//     4 x { GEGLU chunk: 2 passes x 5 k-tiles x 2 halves | FF-out partial over that hidden chunk: 5 k-tiles x 2 halves }, proj_out: 5 x 2 x {hi, lo}
-// so the prologue of GEMM n + 1 is in flight under the epilogue of GEMM n.  The hidden dimension is walked in chunks of 320: the
-// GEGLU output exists only as a 32 x 320 fp16 tile in LDS, consumed as K-chunk h of the FF-out accumulation (k ascending: the
-// same fp32 additions in the same order as the unsplit launches it replaces -- outputs are bit-identical to them).
+// strip in LDS (the LayerNorm-folded rows, then the GEGLU output chunk, then the split-fp16 halves of the FF output).  What streams
+// is the WEIGHTS, all 2.8 MB of them, through one LDS-DMA ring that never drains between GEMMs.  The unit of the ring is 160 weight
+// rows x 64 k (20 KB); five COMPUTE waves side by side own one 32 x 32 MFMA tile of it each (wave w = packed columns [64 w, 64 w + 64)
+// of every 320-column pass: even unit = its first 32 columns, odd unit = its second 32 -- a GEGLU value / gate pair).
 //
-// Every byte arrives by LDS-DMA (one in-order vmcnt class: counted waits are exact) except the strip's residual rows, which are
-// requested first of all and covered by the one full drain of the prologue (register-destined loads and LDS-DMA do not retire
-// through one in-order queue: profiles/gn_fold_r03.txt); there are no global stores before the final epilogue.
+// A sixth wave is the LOADER: it alone issues every LDS-DMA of the ring (20 instructions of 1 KB per unit, ~20 cycles each) and alone
+// waits for them (one in-order vmcnt queue, counted waits are exact); the compute waves never touch vector memory between the
+// prologue and the final epilogue, so nothing they do -- MFMA chains, the GEGLU arithmetic -- ever sits behind a blocked DMA issue
+// (the first version let all five waves issue their share: every wave was stalled ~80 cycles per instruction on the shared address
+// path and stream and compute serialised: 700 cycles per unit where the stream alone takes 500 and the MFMAs alone 300;
+// profiles/ff_tail_r05.txt).  One raw s_barrier per unit is the whole protocol: arriving, the loader has seen unit g land and the
+// compute waves have finished reading unit g - 1, whose stage the loader then refills with unit g + NS - 1.
+//
+// The flat schedule of units (kFtTab):   P0(0) P1(0) | P0(1) P1(1) FF(0) | P0(2) P1(2) FF(1) | P0(3) P1(3) FF(2) | FF(3) | proj_out
+// P0 / P1(h) = the two 320-column GEGLU passes of hidden chunk h (5 k-tiles x 2 halves each), FF(h) = the FF-out partial over
+// hidden chunk h (all 320 output columns, k = 320 h ... 320 h + 319: k ascending over the launch -- the same fp32 additions in the
+// same order as the unsplit GEMMs this replaces, outputs bit-identical to them).  The GEGLU arithmetic of a pass (LayerNorm-fold
+// correction, erf GELU, value * gate: ~45 VALU instructions per output, 16 outputs per lane) is software-pipelined INTO the next
+// block of units, two accumulator rows per unit: the pass's accumulators stay in registers while the next pass runs into a second
+// set, the fp16 results land in one of two hidden-chunk strips, and FF(h) runs one block later, when both passes of chunk h are
+// complete.  (Run after the pass as one piece the arithmetic stalled the ring for 5800 cycles eight times: 27 % of the kernel.)
+//
+// Register-destined loads (the token-stream rows of the FF-out residual) are issued by the compute waves, whose vmcnt then counts
+// nothing else: register loads and LDS-DMA do not retire through one in-order queue (profiles/gn_fold_r03.txt), here they never
+// share one.
+#include <utility>
+
 #include "igemm_dev.h"
 
 namespace sdmi {
 namespace {
 
 constexpr int RC_ROWS = 32;                    // token rows per workgroup
-constexpr int RC_NW = 5, RC_NT = RC_NW * 64;   // five waves: 320 threads
-constexpr int RC_UROWS = 160;                  // weight rows per unit (one 32-row MFMA tile per wave)
+constexpr int RC_NWC = 5;                      // compute waves (threads 0 .. 319)
+constexpr int RC_NTC = RC_NWC * 64;
+constexpr int RC_NT = RC_NTC + 64;             // + the loader wave
+constexpr int RC_UROWS = 160;                  // weight rows per unit (one 32-row MFMA tile per compute wave)
 constexpr int RC_UNIT = RC_UROWS * 128;        // 20 KB: 160 rows x 64 k fp16
-constexpr int RC_LPT = RC_UNIT / (RC_NT * 16); // LDS-DMA instructions per thread and unit (4)
-constexpr int RC_NS = 5;                       // ring depth
+constexpr int RC_UPIECES = RC_UNIT / 1024;     // LDS-DMA instructions per unit (20, all issued by the loader wave)
+constexpr int RC_NS = 4;                       // ring depth (3, 4 and 5 measured the same)
 
-// The flat schedule of weight units of ff_tail_kernel<320>, as {source byte offset of the unit inside its weight matrix (row0 * row
-// pitch + k offset), which matrix}: read with scalar loads one unit ahead of its issue.  Generated by the same loop nest the kernel
-// consumes the units in.
+// ---- the flat schedule of weight units of ff_tail_kernel<320>, in consumption order ------------------------------------------
 constexpr int FT_C = 320, FT_KT = FT_C / 64, FT_HID = 4 * FT_C, FT_NCHUNK = 4;
-constexpr int FT_NU = FT_NCHUNK * (2 * 2 * FT_KT + 2 * FT_KT) + 2 * 2 * FT_KT;      // 140
-struct FtUnitTab { int soff[FT_NU]; int sel[FT_NU]; };       // sel: 0 GEGLU weights (pitch C), 1 FF-out (pitch 4C), 2 proj_out split-fp16 (pitch 3C)
+constexpr int FT_BLK = 2 * FT_KT;                                          // units per block (10)
+constexpr int FT_NU = (3 * FT_NCHUNK) * FT_BLK + 2 * FT_BLK;              // 12 GEGLU / FF-out blocks + proj_out {hi, lo} pairs (140)
+struct FtUnitTab {
+  int soff[FT_NU];      // source byte offset of the unit inside its weight matrix: row0 * row pitch + k offset
+  int sel[FT_NU];       // 0 GEGLU weights (row pitch C), 1 FF-out (4C), 2 proj_out split-fp16 (3C)
+  int aux[FT_NU];       // at the barrier of unit g: >= 0: issue the {cs, d} column terms of that hidden chunk; -2: prefetch the x_in rows
+};
 constexpr FtUnitTab ft_make_tab() {
   FtUnitTab t{};
   int u = 0;
-  for (int h = 0; h < FT_NCHUNK; ++h) {
-    for (int pass = 0; pass < 2; ++pass)
+  for (int i = 0; i < FT_NU; ++i) t.aux[i] = -1;
+  for (int h = 0; h <= FT_NCHUNK; ++h) {
+    if (h < FT_NCHUNK) {
+      for (int pass = 0; pass < 2; ++pass) {
+        // the next chunk's column terms go into the buffer whose last reader was the carried arithmetic of P1(h - 1), inside P0(h)
+        if (pass == 1 && h + 1 < FT_NCHUNK) t.aux[u] = h + 1;
+        for (int kt = 0; kt < FT_KT; ++kt)
+          for (int half = 0; half < 2; ++half) { t.soff[u] = (2 * FT_C * h + FT_C * pass + 32 * half) * (FT_C * 2) + kt * 128; t.sel[u] = 0; ++u; }
+      }
+    } else {
+      t.aux[u] = -2;
+    }
+    if (h >= 1)
       for (int kt = 0; kt < FT_KT; ++kt)
-        for (int half = 0; half < 2; ++half) { t.soff[u] = (2 * FT_C * h + FT_C * pass + 32 * half) * (FT_C * 2) + kt * 128; t.sel[u] = 0; ++u; }
-    for (int kt = 0; kt < FT_KT; ++kt)
-      for (int half = 0; half < 2; ++half) { t.soff[u] = (32 * half) * (FT_HID * 2) + (FT_C * h + 64 * kt) * 2; t.sel[u] = 1; ++u; }
+        for (int half = 0; half < 2; ++half) { t.soff[u] = (32 * half) * (FT_HID * 2) + (FT_C * (h - 1) + 64 * kt) * 2; t.sel[u] = 1; ++u; }
   }
   for (int kt = 0; kt < FT_KT; ++kt)
     for (int half = 0; half < 2; ++half)
@@ -64,117 +93,143 @@ __device__ const FtUnitTab kFtTab = ft_make_tab();
 __device__ __forceinline__ int strip_off(int row, int col) {
   return (col >> 6) * (RC_ROWS * 128) + row * 128 + (((((col & 63) >> 3)) ^ ((row >> 1) & 7)) << 4) + (col & 7) * 2;
 }
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): loops whose index must be a constant (accumulator registers)
+template <int... I, class F>
+__device__ __forceinline__ void rc_static_for_impl(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void rc_static_for(F&& f) { rc_static_for_impl(std::make_integer_sequence<int, N>{}, f); }
 #endif
 
-// ABL (timing build only, -DSDMI_RC_TIMING; WRONG results): 1 = no fragment reads / MFMAs / epilogue arithmetic (the stream and its
-// barriers alone), 2 = no refills after the prologue (the compute side alone), 3 = no GEGLU / FF-out epilogue arithmetic, 4 = no barriers
-template <int C, int ABL = 0>
+// ABL (timing build only, -DSDMI_RC_TIMING; WRONG results): 1 = the compute waves only keep the barriers (the stream alone),
+// 2 = the loader only keeps the barriers (the compute side alone), 3 = no GEGLU arithmetic
+template <int C, int ABL = 0, int NS = RC_NS>
 __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  static_assert(C == 320, "unit geometry: five waves x 64 columns = C");
+  static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C; the unit table is generated for it");
   constexpr int KT = C / 64;                          // k-tiles of a K = C GEMM piece (5)
   constexpr int XBYTES = RC_ROWS * C * 2;             // one operand strip (20 KB)
   constexpr int HID = 4 * C, NCHUNK = HID / C;        // hidden dimension walked in chunks of C (4)
-  constexpr int UPC = 2 * 2 * KT + 2 * KT;            // units per chunk: two GEGLU passes + the FF-out partial (30)
-  constexpr int NU = NCHUNK * UPC + 2 * 2 * KT;       // + proj_out {hi, lo} pairs (140)
-  constexpr int AUXB = 2 * (2 * C) * 4;               // {cs, d} of one chunk's 2C packed GEGLU columns (5 KB = one piece per thread)
-  constexpr int RING = RC_NS * RC_UNIT;
-  constexpr int OFF_XA = RING, OFF_XG = OFF_XA + XBYTES, OFF_AUX = OFF_XG + XBYTES, OFF_TAB = OFF_AUX + 2 * AUXB;
+  constexpr int NU = FT_NU;
+  constexpr int AUXB = 2 * (2 * C) * 4;               // {cs, d} of one chunk's 2C packed GEGLU columns (5 KB)
+  constexpr int RING = NS * RC_UNIT;
+  constexpr int OFF_XA = RING, OFF_XG = OFF_XA + XBYTES, OFF_AUX = OFF_XG + 2 * XBYTES, OFF_TAB = OFF_AUX + 2 * AUXB;
   constexpr int LDS_TOTAL = OFF_TAB + RC_ROWS * 8;
-  static_assert(AUXB == RC_NT * 16, "one aux piece per thread");
-  static_assert(XBYTES == RC_LPT * RC_NT * 16, "operand strip = LPT pieces per thread");
-  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+  constexpr int LD_WAIT = RC_UPIECES * (NS - 2);      // loader: the NS - 2 youngest units may still be in flight
+  static_assert(AUXB == 5 * 1024 && XBYTES == 4 * RC_NTC * 16, "piece counts");
+  static_assert(NS >= 3 && LD_WAIT + RC_UPIECES <= 63 && LD_WAIT <= 48 && LD_WAIT >= 5, "vmcnt is a 6-bit counter");
+  static_assert(RING >= RC_NWC * 32 * 68 * 4, "the final epilogue turns its slabs through the ring");
 #ifdef SDMI_RC_TIMING
   constexpr int OFF_DBG = LDS_TOTAL;                  // 128 cycle stamps of wave 0 (s_memtime), dumped at the end
+  static_assert(LDS_TOTAL + 1024 <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL + 1024];
   int n_stamp = 0;
 #define RC_STAMP() do { if (threadIdx.x == 0 && n_stamp < 128) ((long long*)(smem + OFF_DBG))[n_stamp] = (long long)__builtin_readcyclecounter(); ++n_stamp; } while (0)
 #else
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
   __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
 #define RC_STAMP() do { } while (0)
 #endif
-  RC_STAMP();
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-  const int l31 = lane & 31, lg = lane >> 5;
   const int m0 = blockIdx.x * RC_ROWS;
   const IGemmParams& ep = rp.epi;
+  constexpr int OOB = (int)0x80000000;
 
-  // ---- register-destined loads first: the strip's token-stream rows in the accumulator layout (lane = column, registers =
-  // rows), the FF-out bias, the LayerNorm row partials ----
-  float T[2][16], bff[2];
+  if (wave_u == RC_NWC) {
+    // =============================== the loader wave ===============================================================================
+    const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)rp.csd, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_gg = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wgg, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ff = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wff2, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_po = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wpo, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)ep.residual, 0, OOB, 0x00020000);
+    // piece p of a unit = LDS rows 8 p ... 8 p + 7 (lane -> row 8 p + lane / 8, 16-byte position lane % 8): weight row
+    // 64 (p / 4) + 8 (p % 4) + lane / 8 of the unit (tile slot p / 4 = the compute wave that owns it), source chunk (lane % 8) ^ swizzle
+    // of the LDS row = (lane % 8) ^ ((4 (p % 2) + lane / 16) % 8): two voffset variants, everything else is scalar
+    const int l8 = lane >> 3, cpos = lane & 7;
+    const int g16_0 = (cpos ^ ((l8 >> 1) & 7)) << 4, g16_1 = (cpos ^ ((4 + (l8 >> 1)) & 7)) << 4;
+    auto issue_unit = [&](int soff, int sel, int stage) {
+      const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_gg : (sel == 1 ? rs_ff : rs_po);
+      const int ldw2 = sel == 0 ? C * 2 : (sel == 1 ? HID * 2 : 3 * C * 2);
+      const int v0 = l8 * ldw2 + g16_0, v1 = l8 * ldw2 + g16_1;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int col = wave * 64 + j * 32 + l31;
-    bff[j] = rp.bff2[col];
+      for (int p = 0; p < RC_UPIECES; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * RC_UNIT + p * 1024), 16,
+                                                 (p & 1) ? v1 : v0, soff + (64 * (p >> 2) + 8 * (p & 3)) * ldw2, 0, SDMI_W_AUX);
+    };
+    auto issue_aux = [&](int h) {                       // {cs, d} of hidden chunk h: 5 KB into the buffer of its parity
 #pragma unroll
-    for (int r = 0; r < 16; ++r) T[j][r] = rp.t[(size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * lg) * C + col];
+      for (int p = 0; p < 5; ++p)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_aux, (__attribute__((address_space(3))) void*)(smem + OFF_AUX + (h & 1) * AUXB + p * 1024), 16,
+                                                 lane * 16, h * AUXB + p * 1024, 0, 0);
+    };
+    auto prefetch_x = [&]() {
+      // one dword of each 128-byte line of the strip's x_in rows (the final epilogue's residual: written several launches ago) into a
+      // dead corner of LDS, so that the epilogue's loads find the lines in the L2
+#pragma unroll
+      for (int p = 0; p < 5; ++p) {
+        const int t = p * 64 + lane;                    // 320 lines: row t / 10, line t % 10
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (__attribute__((address_space(3))) void*)(smem + OFF_AUX + p * 256), 4,
+                                                 ((m0 + t / 10) * ep.ldr + (t % 10) * 32) * 4, 0, 0, 0);
+      }
+    };
+    auto desc = [&](int u, int& soff, int& sel) {        // (past the end: the last unit again -- in bounds, never consumed)
+      u = min(u, NU - 1);
+      soff = __builtin_amdgcn_readfirstlane(kFtTab.soff[u]);
+      sel = __builtin_amdgcn_readfirstlane(kFtTab.sel[u]);
+    };
+    if constexpr (ABL != 2) {
+      issue_aux(0);
+#pragma unroll
+      for (int s = 0; s < NS - 1; ++s) {
+        if (s == 2) wait_vmcnt<LD_WAIT>();              // (5 + 40 in flight: make room in the 6-bit counter)
+        issue_unit(kFtTab.soff[s], kFtTab.sel[s], s);
+      }
+    }
+    int nxt = NS - 1, d_soff, d_sel, d_aux;
+    desc(NS - 1, d_soff, d_sel);
+    d_aux = __builtin_amdgcn_readfirstlane(kFtTab.aux[0]);
+    for (int g = 0; g < NU; ++g) {
+      if constexpr (ABL != 2) wait_vmcnt<LD_WAIT>();    // unit g has landed
+      asm volatile("s_barrier" ::: "memory");           // ... and the compute waves are done with unit g - 1
+      if constexpr (ABL != 2) {
+        if (d_aux != -1) {                              // (wave-uniform; 4 times per launch)
+          wait_vmcnt<LD_WAIT - 5>();
+          if (d_aux >= 0) issue_aux(d_aux); else prefetch_x();
+        }
+        issue_unit(d_soff, d_sel, nxt);
+      }
+      desc(g + NS, d_soff, d_sel);
+      d_aux = __builtin_amdgcn_readfirstlane(kFtTab.aux[min(g + 1, NU - 1)]);
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+    wait_vmcnt<0>();                                    // the surplus refills: the ring becomes the epilogue's scratch
+    asm volatile("s_barrier" ::: "memory");
+    return;                                             // (a barrier only waits for the waves that are still alive)
   }
+
+  // ================================= the five compute waves ==========================================================================
+  const int l31 = lane & 31, lg = lane >> 5;
+  RC_STAMP();
+  // LayerNorm row partials (register loads) and this wave's share of the LayerNorm-folded operand strip (LDS-DMA): the only vector
+  // memory the compute waves touch before the FF-out residual
   IGemmParams lq;                                       // (lnf_request / lnf_finish read these four fields)
   lq.lnf_part = rp.lnp; lq.lnf_npart = C / 32; lq.M = ep.M; lq.lnf_eps = rp.ln_eps;
   float2 lnf_pv[LNF_MAXP];
   if (tid < RC_ROWS) lnf_request(lq, m0 + tid, lnf_pv);
-
-  // ---- LDS-DMA plumbing ----
-  constexpr int OOB = (int)0x80000000;
-  const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc((void*)rp.ln, 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)rp.csd, 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_gg = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wgg, 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_ff = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wff2, 0, OOB, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rs_po = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wpo, 0, OOB, 0x00020000);
-  // piece i of a 20 KB block: 16 bytes at block offset (i * 320 + tid) * 16 = LDS row (i * 320 + tid) >> 3, chunk position tid & 7
-  int w_rowterm[RC_LPT], w_g16[RC_LPT];                 // weight unit: which weight row (relative), which 16-byte source chunk
+  {
+    const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc((void*)rp.ln, 0, OOB, 0x00020000);
 #pragma unroll
-  for (int i = 0; i < RC_LPT; ++i) {
-    const int q = i * RC_NT + tid;
-    const int r = q >> 3;                               // LDS row of the unit: tile slot r / 32 (the wave that owns it), row r % 32
-    w_rowterm[i] = 64 * (r >> 5) + (r & 31);            // wave w owns packed columns [64 w, 64 w + 64): even unit = first 32, odd = second
-    w_g16[i] = ((q & 7) ^ ((r >> 1) & 7)) << 4;
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * RC_NTC + tid;                   // 16 bytes at strip offset 16 q: k-tile q / 256, row (q / 8) % 32, position q % 8
+      const int kt = q >> 8, row = (q >> 3) & 31;
+      const int gch = (q & 7) ^ ((row >> 1) & 7);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ln, (__attribute__((address_space(3))) void*)(smem + OFF_XA + (i * RC_NTC + wave_u * 64) * 16), 16,
+                                               ((m0 + row) * C + kt * 64 + gch * 8) * 2, 0, 0, 0);
+    }
   }
-  auto lds_dst = [&](int base, int i) {
-    return (__attribute__((address_space(3))) void*)(smem + base + (i * RC_NT + wave_u * 64) * 16);
-  };
-  // weight unit `d` (its table entry) of the flat schedule into ring stage `stage`
-  auto issue_unit = [&](int soff, int sel, int stage) {
-    const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_gg : (sel == 1 ? rs_ff : rs_po);
-    const int ldw2 = sel == 0 ? C * 2 : (sel == 1 ? HID * 2 : 3 * C * 2);
-#pragma unroll
-    for (int i = 0; i < RC_LPT; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds_dst(stage * RC_UNIT, i), 16, w_rowterm[i] * ldw2 + w_g16[i], soff, 0, SDMI_W_AUX);
-  };
-  // table entry of unit u (past the end: the last unit again -- in bounds, never consumed), as scalars
-  auto unit_desc = [&](int u, int& soff, int& sel) {
-    u = min(u, NU - 1);
-    soff = __builtin_amdgcn_readfirstlane(kFtTab.soff[u]);
-    sel = __builtin_amdgcn_readfirstlane(kFtTab.sel[u]);
-  };
-  auto issue_aux = [&](int h) {                         // {cs, d} of chunk h: 5 KB, one piece per thread
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_aux, (__attribute__((address_space(3))) void*)(smem + OFF_AUX + (h & 1) * AUXB + wave_u * 1024),
-                                             16, tid * 16, h * AUXB, 0, 0);
-  };
-
-  // ---- prologue: the LayerNorm-folded operand strip, chunk 0's column terms, the first NS - 1 weight units ----
-#pragma unroll
-  for (int i = 0; i < RC_LPT; ++i) {
-    const int q = i * RC_NT + tid;
-    const int kt = q >> 8, row = (q >> 3) & 31;
-    const int gch = (q & 7) ^ ((row >> 1) & 7);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ln, lds_dst(OFF_XA, i), 16, ((m0 + row) * C + kt * 64 + gch * 8) * 2, 0, 0, 0);
-  }
-  issue_aux(0);
-#pragma unroll
-  for (int s = 0; s < RC_NS - 1; ++s) issue_unit(kFtTab.soff[s], kFtTab.sel[s], s);
-  // the one full drain: register loads and LDS-DMA are two retirement classes, so only vmcnt(0) says that BOTH have landed; from
-  // here to the final epilogue every vector-memory operation is an LDS-DMA and the counted waits below are exact
-  wait_vmcnt<0>();
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    asm volatile("" : "+v"(bff[j]));
-#pragma unroll
-    for (int r = 0; r < 16; ++r) asm volatile("" : "+v"(T[j][r]));     // (pins the loads in front of the drain)
-  }
+  wait_vmcnt<0>();                                      // (both kinds: the only full drain of these waves before the residual)
   float2* const tab = (float2*)(smem + OFF_TAB);        // {mean, rstd} of the strip's rows
   if (tid < RC_ROWS) {
     float mu, rs_;
@@ -183,127 +238,130 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
   }
   RC_STAMP();
 
-  // ---- the unit pipeline.  Invariant: before unit g is consumed, units <= g + NS - 2 have been issued; consuming it = counted
-  // wait (the NS - 2 younger units may still fly) + barrier (everybody's share landed; everybody finished unit g - 1), fragment
-  // reads, refill of unit g - 1's stage with unit g + NS - 1, MFMAs ----
   const int rsw = (l31 >> 1) & 7;
   const int a_frag = l31 * 128, b_frag = (wave * 32 + l31) * 128;
-  int cur = 0, nxt = RC_NS - 1, iu = RC_NS - 1;
-  int d_soff, d_sel;                                    // table entry of unit iu, fetched one unit ahead
-  unit_desc(iu, d_soff, d_sel);
-  auto unit_begin = [&]() {
-    wait_vmcnt<RC_LPT*(RC_NS - 2)>();
-    if constexpr (ABL == 4) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  };
-  auto unit_refill = [&]() {
-    if constexpr (ABL != 2) issue_unit(d_soff, d_sel, nxt);
-    ++iu;
-    unit_desc(iu, d_soff, d_sel);
-    nxt = (nxt + 1 == RC_NS) ? 0 : nxt + 1;
-  };
-  auto unit_end = [&]() { cur = (cur + 1 == RC_NS) ? 0 : cur + 1; };
+  int cur = 0;
+  auto unit_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto unit_end = [&]() { cur = (cur + 1 == NS) ? 0 : cur + 1; };
   auto frag = [&](int base, int ks) { return *(const f16x8*)(smem + base + (((ks * 2 + lg) ^ rsw) << 4)); };
-  // the two units (column halves) of k-tile kt of a plain GEMM piece: acc0 / acc1 += A[32 x 64 k] * W_unit[32 x 64 k]^T; the A
-  // fragments are read once for both.  aux_h >= 0: chunk aux_h's column terms ride in front of the first refill (older than it)
-  auto ktile_mma = [&](int a_base, int kt, f32x16& acc0, f32x16& acc1, int aux_h) {
-    f16x8 fa[4], fb[4];
-    unit_begin();
-    if constexpr (ABL != 1) {
+  // One block of ten units = the five k-tiles of a K = C GEMM piece, two column halves each: acc0 / acc1 += A[32 x 64 k] * W_unit^T
+  // (the A fragments are read once per k-tile).  carry(u): the arithmetic carried by unit u of the block (u is a compile-time
+  // constant: accumulator registers are addressed by it).
+  auto block = [&](int a_base, f32x16& acc0, f32x16& acc1, auto&& carry) {
+    rc_static_for<KT>([&](auto ktc) {
+      constexpr int kt = decltype(ktc)::value;
+      f16x8 fa[4], fb[4];
+      unit_sync();
+      if constexpr (ABL != 1) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[ks] = frag(a_base + kt * (RC_ROWS * 128) + a_frag, ks);
+        for (int ks = 0; ks < 4; ++ks) fa[ks] = frag(a_base + kt * (RC_ROWS * 128) + a_frag, ks);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
-    }
-    if (aux_h >= 0) issue_aux(aux_h);
-    unit_refill();
-    if constexpr (ABL != 1) {
+        for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], acc0, 0, 0, 0);
-    }
-    unit_end();
-    unit_begin();
-    if constexpr (ABL != 1) {
+        for (int ks = 0; ks < 4; ++ks) acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], acc0, 0, 0, 0);
+        carry(std::integral_constant<int, 2 * kt>{});
+      }
+      unit_end();
+      unit_sync();
+      if constexpr (ABL != 1) {
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
-    }
-    unit_refill();
-    if constexpr (ABL != 1) {
+        for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], acc1, 0, 0, 0);
-    }
-    unit_end();
-    RC_STAMP();
+        for (int ks = 0; ks < 4; ++ks) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], acc1, 0, 0, 0);
+        carry(std::integral_constant<int, 2 * kt + 1>{});
+      }
+      unit_end();
+      RC_STAMP();
+    });
   };
-
-  f32x16 acc2[2];                                       // FF-out accumulators (all hidden chunks)
+  auto no_carry = [](auto) {};
+  // The GEGLU arithmetic of one finished pass, two accumulator rows per unit (units 0 ... 7 of the carrying block), in the accumulator
+  // layout (lane = column, registers = rows): LayerNorm fold (igemm_epilogue's expression), value * gelu(gate), fp16 into the
+  // hidden-chunk strip of chunk h: column 160 pass + 32 wave + l31.  av / ag: the value / gate accumulators of this wave.
+  auto geglu_rows = [&](auto uc, const f32x16& av, const f32x16& ag, int h, int pass) {
+    constexpr int u = decltype(uc)::value;
+    if constexpr (u < 8 && ABL != 3) {
+      const float* const aux = (const float*)(smem + OFF_AUX + (h & 1) * AUXB);
+      const int pc = C * pass + 64 * wave + l31;        // packed column of the value tile inside the chunk; gate = pc + 32
+      const float cs_v = aux[pc], cs_g = aux[pc + 32], d_v = aux[2 * C + pc], d_g = aux[2 * C + pc + 32];
+      const int oc = (C / 2) * pass + 32 * wave + l31;
+      const int xg = OFF_XG + (h & 1) * XBYTES;
 #pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc2[j][r] = 0.f;
-
-  for (int h = 0; h < NCHUNK; ++h) {
-    for (int pass = 0; pass < 2; ++pass) {
-      f32x16 acc[2];
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-      ktile_mma(OFF_XA, 0, acc[0], acc[1], (pass == 0 && h + 1 < NCHUNK) ? h + 1 : -1);
-      for (int kt = 1; kt < KT; ++kt) ktile_mma(OFF_XA, kt, acc[0], acc[1], -1);
-      // GEGLU epilogue in the accumulator layout: LayerNorm fold (igemm_epilogue's expression), value * gelu(gate), fp16 into the
-      // hidden-chunk strip: output column 160 pass + 32 wave + l31 of the chunk
-      if constexpr (ABL != 1 && ABL != 3) {
-        const float* const aux = (const float*)(smem + OFF_AUX + (h & 1) * AUXB);
-        const int pc = C * pass + 64 * wave + l31;      // packed column of the value tile inside the chunk; gate = pc + 32
-        const float cs_v = aux[pc], cs_g = aux[pc + 32], d_v = aux[2 * C + pc], d_g = aux[2 * C + pc + 32];
-        const int oc = (C / 2) * pass + 32 * wave + l31;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;
-          const float2 mr = tab[row];
-          const float val = fmaf(mr.y, acc[0][r] - mr.x * cs_v, d_v);
-          const float gate = fmaf(mr.y, acc[1][r] - mr.x * cs_g, d_g);
-          *(f16*)(smem + OFF_XG + strip_off(row, oc)) = (f16)(val * gelu_erf(gate));
-        }
+      for (int i = 0; i < 2; ++i) {
+        constexpr int r0 = 2 * u;
+        const int r = r0 + i;
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;
+        const float2 mr = tab[row];
+        const float val = fmaf(mr.y, av[r] - mr.x * cs_v, d_v);
+        const float gate = fmaf(mr.y, ag[r] - mr.x * cs_g, d_g);
+        *(f16*)(smem + xg + strip_off(row, oc)) = (f16)(val * gelu_erf(gate));
       }
     }
-    for (int kt = 0; kt < KT; ++kt) ktile_mma(OFF_XG, kt, acc2[0], acc2[1], -1);
+  };
+  auto zero2 = [](f32x16 (&a)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[j][r] = 0.f;
+  };
+
+  f32x16 accA[2], accB[2], acc2[2];                     // GEGLU pass 0 / pass 1 of the running chunk, FF-out (all hidden chunks)
+  zero2(acc2); zero2(accB);
+  for (int h = 0; h < NCHUNK; ++h) {
+    // P0(h), carrying the arithmetic of P1(h - 1)
+    zero2(accA);
+    block(OFF_XA, accA[0], accA[1], [&](auto uc) { if (h > 0) geglu_rows(uc, accB[0], accB[1], h - 1, 1); });
+    // P1(h), carrying the arithmetic of P0(h)
+    zero2(accB);
+    block(OFF_XA, accB[0], accB[1], [&](auto uc) { geglu_rows(uc, accA[0], accA[1], h, 0); });
+    // FF(h - 1): both passes of chunk h - 1 are complete (the second one since P0(h)); the last one carries P1(3)
+    if (h > 0) block(OFF_XG + ((h - 1) & 1) * XBYTES, acc2[0], acc2[1], [&](auto uc) { if (h == NCHUNK - 1) geglu_rows(uc, accB[0], accB[1], h, 1); });
   }
-  // ---- FF-out epilogue: t' = (acc + bias) + t (the launch's expression), then the split-fp16 operand of proj_out: hi over the
-  // LayerNorm strip, lo over the hidden-chunk strip (both dead now; the last FF-out unit may still be read by a slower wave) ----
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-  RC_STAMP();
+  // FF(3); its residual rows (the fp32 token stream, accumulator layout) and bias are requested in front of it: nothing else of these
+  // waves is in the vmcnt queue, the drain behind the block is exact and free
+  float T[2][16], bff[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int col = wave * 64 + j * 32 + l31;
+    bff[j] = rp.bff2[col];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;
-      const float v = acc2[j][r] + bff[j] + T[j][r];
-      const f16 hi = (f16)v;
-      const int o = strip_off(row, col);
-      *(f16*)(smem + OFF_XA + o) = hi;
-      *(f16*)(smem + OFF_XG + o) = (f16)(v - (float)hi);
+    for (int r = 0; r < 16; ++r) T[j][r] = rp.t[(size_t)(m0 + (r & 3) + 8 * (r >> 2) + 4 * lg) * C + col];
+  }
+  block(OFF_XG + ((NCHUNK - 1) & 1) * XBYTES, acc2[0], acc2[1], no_carry);
+  wait_vmcnt<0>();
+  // ---- FF-out epilogue: t' = (acc + bias) + t (the launch's expression), then the split-fp16 operand of proj_out: hi over the
+  // LayerNorm strip (last read in P1(3)), lo over hidden-chunk strip 0 (last read by FF(2)) ----
+  if constexpr (ABL != 1) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wave * 64 + j * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * lg;
+        const float v = acc2[j][r] + bff[j] + T[j][r];
+        const f16 hi = (f16)v;
+        const int o = strip_off(row, col);
+        *(f16*)(smem + OFF_XA + o) = hi;
+        *(f16*)(smem + OFF_XG + o) = (f16)(v - (float)hi);
+      }
     }
   }
+  RC_STAMP();
   // ---- proj_out as split-fp16: per (k-tile, half) the hi unit only parks its fragments, the lo unit runs the three products of
   // every k-step in gemm_split16_kernel's order (a_hi w_hi, a_lo w_hi, a_hi w_lo) ----
   f32x16 acc[1][2];
-#pragma unroll
-  for (int j = 0; j < 2; ++j)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[0][j][r] = 0.f;
-  for (int kt = 0; kt < KT; ++kt) {
+  zero2(acc[0]);
+  rc_static_for<KT>([&](auto ktc) {
+    constexpr int kt = decltype(ktc)::value;
     f16x8 ah[4], al[4];
-#pragma unroll
-    for (int half = 0; half < 2; ++half) {
+    rc_static_for<2>([&](auto hc) {
+      constexpr int half = decltype(hc)::value;
       f16x8 bh[4], bl[4];
-      unit_begin();
+      unit_sync();
       if constexpr (ABL != 1) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bh[ks] = frag(cur * RC_UNIT + b_frag, ks);
-        if (half == 0) {
+        if constexpr (half == 0) {
 #pragma unroll
           for (int ks = 0; ks < 4; ++ks) {
             ah[ks] = frag(OFF_XA + kt * (RC_ROWS * 128) + a_frag, ks);
@@ -311,15 +369,11 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
           }
         }
       }
-      unit_refill();
       unit_end();
-      unit_begin();
+      unit_sync();
       if constexpr (ABL != 1) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) bl[ks] = frag(cur * RC_UNIT + b_frag, ks);
-      }
-      unit_refill();
-      if constexpr (ABL != 1) {
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           acc[0][half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks], acc[0][half], 0, 0, 0);
@@ -328,13 +382,13 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
         }
       }
       unit_end();
-    }
+    });
     RC_STAMP();
-  }
-  wait_vmcnt<0>();                                       // (the surplus refills)
+  });
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // the loader has drained its queue: the ring is free
   RC_STAMP();
   // the shared GEMM epilogue on a 32 x 320 tile of five 64-column waves: bias + x_in, fp32 out (+ fp16 copy), GroupNorm statistics
-  igemm_epilogue<RC_ROWS, C, 1, RC_NW, RING>(ep, acc, m0, 0, 0, (int)blockIdx.x, 0, smem);
+  igemm_epilogue<RC_ROWS, C, 1, RC_NWC, RING>(ep, acc, m0, 0, 0, (int)blockIdx.x, 0, smem);
 #ifdef SDMI_RC_TIMING
   RC_STAMP();
   __syncthreads();
@@ -362,6 +416,7 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   SDMI_CHECK(ff_tail_supported(C, e.M, e.Hout * e.Wout), "ff_tail: C = 320, rows (per sample) multiples of 32");
   SDMI_CHECK(p.ln && p.lnp && p.csd && p.wgg && p.wff2 && p.bff2 && p.t && p.wpo, "ff_tail: null operand");
   SDMI_CHECK(e.mode == EPI_PLAIN && e.K == C && e.M == e.B * e.Hout * e.Wout && e.out_f32 && e.ldo % 4 == 0, "ff_tail: proj_out descriptor");
+  SDMI_CHECK(e.residual && e.ldr >= C, "ff_tail: proj_out adds the SpatialTransformer's input (residual)");
   SDMI_CHECK(!e.lnf_part && !e.lnp_out && !e.f16_scale && !e.ln_out && !e.out_lo && !e.rowvec, "ff_tail: plain proj_out epilogue only");
   if (e.gn_n) {
     SDMI_CHECK(e.gn_n <= 2 && (e.Hout * e.Wout) % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
@@ -379,17 +434,19 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   ProfScope ps("ff_tail_32x320w5", 2.0 * M * (8.0 * C * C + 4.0 * C * C + (double)C * C),
                M * C * (2.0 + 4.0 + 4.0 + 4.0 + (e.out_f16 ? 2.0 : 0.0)) + 13.0 * C * C * 2.0, stream,
                2.0 * M * (8.0 * C * C + 4.0 * C * C + 3.0 * C * C));
+  const dim3 grid(e.M / RC_ROWS), blk(RC_NT);
 #ifdef SDMI_RC_TIMING
   q.dbg = g_rc_dbg;
   switch (g_rc_abl) {
-    case 1: hipLaunchKernelGGL((ff_tail_kernel<320, 1>), dim3(e.M / RC_ROWS), dim3(RC_NT), 0, stream, q); break;
-    case 2: hipLaunchKernelGGL((ff_tail_kernel<320, 2>), dim3(e.M / RC_ROWS), dim3(RC_NT), 0, stream, q); break;
-    case 3: hipLaunchKernelGGL((ff_tail_kernel<320, 3>), dim3(e.M / RC_ROWS), dim3(RC_NT), 0, stream, q); break;
-    case 4: hipLaunchKernelGGL((ff_tail_kernel<320, 4>), dim3(e.M / RC_ROWS), dim3(RC_NT), 0, stream, q); break;
-    default: hipLaunchKernelGGL((ff_tail_kernel<320, 0>), dim3(e.M / RC_ROWS), dim3(RC_NT), 0, stream, q); break;
+    case 1: hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, blk, 0, stream, q); break;
+    case 2: hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, blk, 0, stream, q); break;
+    case 3: hipLaunchKernelGGL((ff_tail_kernel<320, 3>), grid, blk, 0, stream, q); break;
+    case 10: hipLaunchKernelGGL((ff_tail_kernel<320, 0, 3>), grid, blk, 0, stream, q); break;     // ring depth 3
+    case 11: hipLaunchKernelGGL((ff_tail_kernel<320, 1, 3>), grid, blk, 0, stream, q); break;
+    default: hipLaunchKernelGGL((ff_tail_kernel<320, 0>), grid, blk, 0, stream, q); break;
   }
 #else
-  hipLaunchKernelGGL((ff_tail_kernel<320>), dim3(e.M / RC_ROWS), dim3(RC_NT), 0, stream, q);
+  hipLaunchKernelGGL((ff_tail_kernel<320>), grid, blk, 0, stream, q);
 #endif
   SDMI_HIP_OK(hipGetLastError());
   return 0;

@@ -114,3 +114,25 @@ def test_vae_round_trip_shapes_and_refusals():
         m.encode_moments(torch.zeros(1, 3, 33, 48, device='cuda'))
     with pytest.raises(RuntimeError, match='no CPU'):
         m.decode(torch.zeros(1, 4, 8, 8))
+
+
+def test_vae_decode_outputs_beyond_2_gb():
+    """Four 768 x 768 images decoded together: the upsampling convs' fp32 outputs are 4 x 604 MB = 2.4 GB, i.e. byte offsets beyond
+    2^31 -- where the write-through (buffer) stores of the GEMM epilogues, the split-K reduce and GroupNorm-apply must take their
+    64-bit form (csrc/common.h sdmi_st_wt16: a 32-bit offset past the 2^31 records would be dropped by the range check, one past
+    2^32 would wrap onto an earlier sample).  Every sample, the last one in particular, must equal its own single-image decode."""
+    m = _model('sd', 0)
+    free, _ = torch.cuda.mem_get_info()
+    if free < 60 << 30:
+        pytest.skip('needs ~40 GB of free HBM')
+    lat = make_vae_inputs(SD_VAE, 4, 96, 96, seed=21).cuda()
+    all4 = m.decode(lat)
+    torch.cuda.synchronize()
+    assert torch.isfinite(all4).all()
+    for i in (0, 3):
+        one = m.decode(lat[i:i + 1])
+        err = (one - all4[i:i + 1]).abs().max().item()
+        print(f'[vae decode 4 x 768x768] sample {i} vs its single-image decode: max-abs {err:.3e}', flush=True)
+        assert err < 2e-3
+    del all4
+    torch.cuda.empty_cache()

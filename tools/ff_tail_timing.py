@@ -30,7 +30,8 @@ def one():
     K.ff_tail(c['ln16'], c['part'], 1e-5, c['csd'], c['wp'], c['wff2'], c['bff2'], c['t'], c['wpo3'], c['bpo'], c['x_in'], out, B, ntok)
 
 
-for abl in (0, 1, 2, 3, 4):
+NAMES = ['P0(0)', 'P1(0)', 'P0(1)', 'P1(1)', 'FF(0)', 'P0(2)', 'P1(2)', 'FF(1)', 'P0(3)', 'P1(3)', 'FF(2)', 'FF(3)']
+for abl in (0, 1, 2, 3, 10, 11):      # 1x: ring depth 3 (x = the ablation)
     dbg_fn(stamps.data_ptr(), abl)
     for _ in range(5):
         one()
@@ -41,22 +42,15 @@ for abl in (0, 1, 2, 3, 4):
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / 30
     st = stamps.cpu().double()
-    # stamp order: 0 entry, 1 prologue done, then per chunk h: 5 + 5 GEGLU k-tile steps, 5 FF-out k-tile steps (15 per chunk),
-    # then FF-out epilogue start (62), 5 proj_out k-tile stamps (63..67), drained (68), end (69)
+    # stamps of wave 0: 0 entry, 1 prologue done, 2 ... 61 one per k-tile step (two units) of the twelve blocks, 62 FF-out epilogue done,
+    # 63 ... 67 the proj_out k-tile steps (four units each), 68 ring drained, 69 end
     d = st[:, 1:70] - st[:, 0:69]
     mean = d.mean(0)
     tot = (st[:, 69] - st[:, 0])
-    line = f'ABL {abl}: {us:7.1f} us per launch | workgroup cycles mean {tot.mean():9.0f} max {tot.max():9.0f} | prologue {mean[0]:7.0f}'
-    for h in range(4):
-        b = 1 + 15 * h
-        line += f' | h{h} geglu {mean[b:b + 10].sum() / 20:6.0f} ff {mean[b + 10:b + 15].sum() / 10:6.0f} cyc/unit'
-    line += f' | ff-epi {mean[61] if False else (st[:, 62] - st[:, 61]).mean():6.0f}'
-    line += f' | proj_out {(st[:, 67] - st[:, 62]).mean() / 20:6.0f} cyc/unit (incl. ff-out epilogue) | drain {(st[:, 68] - st[:, 67]).mean():6.0f} | epilogue {(st[:, 69] - st[:, 68]).mean():6.0f}'
-    print(line, flush=True)
+    print(f'ABL {abl}: {us:7.1f} us per launch | workgroup cycles mean {tot.mean():9.0f} max {tot.max():9.0f} | prologue {mean[0]:6.0f} | '
+          f'FF-out epilogue {mean[61]:6.0f} | proj_out {mean[62:67].sum() / 20:5.0f} cyc/unit | drain {mean[67]:6.0f} | final epilogue {mean[68]:6.0f}', flush=True)
+    print('    cycles per unit by block: ' + '  '.join(f'{n} {mean[1 + 5 * b:6 + 5 * b].sum() / 10:4.0f}' for b, n in enumerate(NAMES)), flush=True)
     if abl == 0:
-        # first k-tile step of each GEGLU pass carries the previous epilogue: print the ten steps of chunk 1
-        print('   chunk 1 per k-tile step (2 units):', ' '.join(f'{v:5.0f}' for v in mean[16:31]), flush=True)
-        per_wg = tot
-        print(f'   per-workgroup total cycles: min {per_wg.min():.0f} p50 {per_wg.median():.0f} max {per_wg.max():.0f}; '
-              f'start skew (stamp 0 spread) {st[:, 0].max() - st[:, 0].min():.0f} cycles', flush=True)
+        print('    P1(1) per k-tile step (2 units):', ' '.join(f'{v:5.0f}' for v in mean[16:21]), '| FF(0):', ' '.join(f'{v:5.0f}' for v in mean[21:26]), flush=True)
+        print(f'    per-workgroup total cycles: min {tot.min():.0f} p50 {tot.median():.0f} max {tot.max():.0f}', flush=True)
 dbg_fn(None, 0)
