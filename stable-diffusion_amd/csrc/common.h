@@ -301,6 +301,31 @@ struct FfTailParams {
 bool ff_tail_supported(int C, int M, int rows_per_sample);
 int launch_ff_tail(const FfTailParams& p, hipStream_t stream);
 
+// Row-strip chain kernel, the HEAD of a SpatialTransformer (rowchain.hip): GroupNorm-apply -> proj_in -> (norm1 folded) q | k | v
+//   t = proj_in(norm(x)) + b;  q | k | v = norm1(t) Wqkv^T        ldm/modules/attention.py:254-256 (norm, proj_in), :212 + :170-176 (attn1's
+// projections) as ONE launch instead of GroupNorm-apply, the split-fp16 proj_in GEMM and the q|k|v GEMM.  Same arithmetic in the same order as
+// those launches (the outputs are the same bits).
+struct StHeadParams {
+  const float* x = nullptr;        // [M][C] fp32: the SpatialTransformer's input (NHWC rows)
+  const long long* gn_acc = nullptr;   // GroupNorm statistics accumulators of x (GroupNormParams::acc, complete before the launch)
+  const float* gn_gamma = nullptr; const float* gn_beta = nullptr; float gn_eps = 1e-6f;
+  const f16* w_in = nullptr;       // [C][3C] split-fp16 proj_in weights [hi | hi | lo]
+  const float* b_in = nullptr;     // [C]
+  float* t = nullptr;              // [M][C] fp32 out: the token stream
+  const float* ln_gamma = nullptr; // norm1 weight: the q|k|v operand is fp16(gamma * t) (IGemmParams::f16_scale), beta lives in lnf_d
+  float ln_eps = 1e-5f;
+  const f16* wqkv = nullptr;       // [3C][C] attn1 to_q | to_k | to_v
+  const float* lnf_cs = nullptr; const float* lnf_d = nullptr;   // [3C] LayerNorm-fold column terms (IGemmParams::lnf_cs / lnf_d)
+  f16* q = nullptr; f16* k = nullptr;  // [B * heads][ntok][dh]
+  f16* vt = nullptr;               // [B * heads][dh][ntok_pad]
+  int M = 0, B = 0, ntok = 0, ntok_pad = 0, heads = 0, dh = 0, C = 0;
+#ifdef SDMI_RC_TIMING
+  long long* dbg = nullptr;
+#endif
+};
+bool st_head_supported(int C, int M, int ntok, int ntok_pad, int heads, int dh);
+int launch_st_head(const StHeadParams& p, hipStream_t stream);
+
 // Flash attention over per-head layouts produced by EPI_HEADS
 struct AttnParams {
   const f16* q = nullptr;    // [BH][nq][d]

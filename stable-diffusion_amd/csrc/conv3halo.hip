@@ -732,7 +732,7 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
-  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   q.magic_w2 = div_magic(p.Wout + 2);
   q.log2w = 0;
@@ -796,7 +796,7 @@ int launch_halo_gn_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
-  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   q.magic_w2 = div_magic(p.Wout + 2);
   q.magic_cpg_in = div_magic((p.c0 + p.c1) / 32);

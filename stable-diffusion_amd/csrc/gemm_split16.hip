@@ -332,7 +332,7 @@ int launch_split16_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
-  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);
@@ -376,7 +376,7 @@ int launch_split16_gn(const IGemmParams& p, hipStream_t stream) {
   q.tile_n_fastest = tile_order_n_fastest(p);
   q.splitk_fused = 0;
   q.epi_vec = epi_vec_ok(p);
-  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   q.magic_cpg_in = div_magic(p.K / 32);
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);

@@ -107,7 +107,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) igemm_kernel(const IGem
 #pragma unroll
   for (int i = 0; i < A_PASSES; ++i) {
     const int m = min(m0 + i * RPP + lrow, p.M - 1);
-    const int b = fast_div(m, p.magic_hw);
+    const int b = fast_div_hw(m, p.magic_hw);
     const int rem = m - b * HWout;
     const int oy = fast_div(rem, p.magic_w), ox = rem - oy * p.Wout;
     const int pb = b * p.Hin * p.Win;
@@ -759,7 +759,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
-  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
   dim3 grid(tiles_m * tiles_n * nsplit), block(WARPS_M * WARPS_N * 64);

@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(NW * 64) igemm5_kernel(const IGemmParams p, co
     const int gch = cpos ^ ((r >> 1) & 7);                         // (BM % 16 == 0: the swizzle of a W row is that of r - BM)
     if (o < OCT_A) {
       const int m = min(m0 + r, p.M - 1);
-      const int b = fast_div(m, p.magic_hw);
+      const int b = fast_div_hw(m, p.magic_hw);
       const int rem = m - b * HWout;
       const int oy = fast_div(rem, p.magic_w), ox = rem - oy * p.Wout;
       const int cy = oy * p.stride, cx = ox * p.stride;
@@ -243,7 +243,7 @@ int launch_cfg5(const IGemmParams& p, int splitk, hipStream_t stream) {
   q.splitk_fused = nsplit > 1 && splitk_fusable(p, BM, BN);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
-  q.magic_hw = div_magic(p.Hout * p.Wout);
+  q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);
   dim3 grid(tiles_m * tiles_n * nsplit), block(NW * 64);

@@ -31,12 +31,14 @@ constexpr int BK = 64;
 
 // exact-erf GELU (F.gelu default, attention.py:43).  erf by Abramowitz-Stegun 7.1.26 (|abs err| <= 1.5e-7, i.e.
 // 3 orders of magnitude below the fp16 rounding of the GEGLU output) -- the libm erff costs ~3x more VALU.
+// 1 / (1 + p z) is the hardware reciprocal (v_rcp_f32, 1 ulp: the IEEE division sequence was 10 of the 37 VALU instructions per GEGLU
+// output, and the GEGLU arithmetic is what the row-strip chain kernel's compute waves are bound by); the sign is one v_bfi_b32.
 __device__ __forceinline__ float gelu_erf(float x) {
   const float z = fabsf(x) * 0.70710678118654752440f;
-  const float t = 1.0f / (1.0f + 0.3275911f * z);
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * z);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float erf_abs = 1.0f - poly * __expf(-z * z);
-  const float erf_v = x < 0.f ? -erf_abs : erf_abs;
+  const float erf_v = __builtin_copysignf(erf_abs, x);
   return 0.5f * x * (1.0f + erf_v);
 }
 
@@ -73,6 +75,13 @@ enum : int { KIND_1X1 = 0, KIND_3X3 = 1, KIND_3X3_UP = 2 };
 // the prologue without the ~40-instruction integer division sequences
 __device__ __forceinline__ int fast_div(int m, unsigned long long magic) {
   return (int)(((unsigned long long)(unsigned)m * magic) >> 40);
+}
+// the row -> sample split m / (Hout * Wout): the dividend is a ROW INDEX (up to B * Hout * Wout), so m * d reaches B * (Hout*Wout)^2 --
+// 1.4e12 > 2^40 for four 768 x 768 first-stage maps, where the 2^40 form returned sample B for the last pixels of the last sample.
+// 2^48 form (magic = ceil(2^48 / d), div_magic_hw): exact for m * d < 2^48; the product m * magic stays below 2^64 because the
+// quotient (a sample index) is < 2^16.
+__device__ __forceinline__ int fast_div_hw(int m, unsigned long long magic) {
+  return (int)(((unsigned long long)(unsigned)m * magic) >> 48);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -647,6 +656,10 @@ __device__ __forceinline__ void igemm_epilogue(const IGemmParams& p_arg, f32x16 
 
 static unsigned long long div_magic(int d) {      // ceil(2^40 / d), see fast_div
   const unsigned long long one = 1ull << 40;
+  return (one + (unsigned long long)d - 1) / (unsigned long long)d;
+}
+static unsigned long long div_magic_hw(int d) {   // ceil(2^48 / d), see fast_div_hw (IGemmParams::magic_hw)
+  const unsigned long long one = 1ull << 48;
   return (one + (unsigned long long)d - 1) / (unsigned long long)d;
 }
 

@@ -45,11 +45,12 @@ namespace {
 constexpr int RC_ROWS = 32;                    // token rows per workgroup
 constexpr int RC_NWC = 5;                      // compute waves (threads 0 .. 319)
 constexpr int RC_NTC = RC_NWC * 64;
-constexpr int RC_NT = RC_NTC + 64;             // + the loader wave
+constexpr int RC_NLD_MAX = 4;                  // loader waves: 1, 2 or 4 (template argument NLD; wave RC_NWC + l issues pieces p = l mod NLD)
 constexpr int RC_UROWS = 160;                  // weight rows per unit (one 32-row MFMA tile per compute wave)
 constexpr int RC_UNIT = RC_UROWS * 128;        // 20 KB: 160 rows x 64 k fp16
 constexpr int RC_UPIECES = RC_UNIT / 1024;     // LDS-DMA instructions per unit (20, all issued by the loader wave)
 constexpr int RC_NS = 4;                       // ring depth (3, 4 and 5 measured the same)
+constexpr int RC_NLD_DEFAULT = 2;
 
 // ---- the flat schedule of weight units of ff_tail_kernel<320>, in consumption order ------------------------------------------
 constexpr int FT_C = 320, FT_KT = FT_C / 64, FT_HID = 4 * FT_C, FT_NCHUNK = 4;
@@ -102,8 +103,8 @@ __device__ __forceinline__ void rc_static_for(F&& f) { rc_static_for_impl(std::m
 
 // ABL (timing build only, -DSDMI_RC_TIMING; WRONG results): 1 = the compute waves only keep the barriers (the stream alone),
 // 2 = the loader only keeps the barriers (the compute side alone), 3 = no GEGLU arithmetic
-template <int C, int ABL = 0, int NS = RC_NS>
-__global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
+template <int C, int NLD, int ABL = 0, int NS = RC_NS>
+__global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTailParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C; the unit table is generated for it");
   constexpr int KT = C / 64;                          // k-tiles of a K = C GEMM piece (5)
@@ -114,9 +115,11 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
   constexpr int RING = NS * RC_UNIT;
   constexpr int OFF_XA = RING, OFF_XG = OFF_XA + XBYTES, OFF_AUX = OFF_XG + 2 * XBYTES, OFF_TAB = OFF_AUX + 2 * AUXB;
   constexpr int LDS_TOTAL = OFF_TAB + RC_ROWS * 8;
-  constexpr int LD_WAIT = RC_UPIECES * (NS - 2);      // loader: the NS - 2 youngest units may still be in flight
+  static_assert(NLD == 1 || NLD == 2 || NLD == 4, "loader waves");
+  constexpr int LPIECES = RC_UPIECES / NLD;           // LDS-DMA instructions per unit and loader wave
+  constexpr int LD_WAIT = LPIECES * (NS - 2);         // a loader: its pieces of the NS - 2 youngest units may still be in flight
   static_assert(AUXB == 5 * 1024 && XBYTES == 4 * RC_NTC * 16, "piece counts");
-  static_assert(NS >= 3 && LD_WAIT + RC_UPIECES <= 63 && LD_WAIT <= 48 && LD_WAIT >= 5, "vmcnt is a 6-bit counter");
+  static_assert(NS >= 3 && LD_WAIT + LPIECES <= 63 && LD_WAIT <= 48 && LD_WAIT >= 5, "vmcnt is a 6-bit counter");
   static_assert(RING >= RC_NWC * 32 * 68 * 4, "the final epilogue turns its slabs through the ring");
 #ifdef SDMI_RC_TIMING
   constexpr int OFF_DBG = LDS_TOTAL;                  // 128 cycle stamps of wave 0 (s_memtime), dumped at the end
@@ -137,8 +140,9 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
   const IGemmParams& ep = rp.epi;
   constexpr int OOB = (int)0x80000000;
 
-  if (wave_u == RC_NWC) {
-    // =============================== the loader wave ===============================================================================
+  if (wave_u >= RC_NWC) {
+    // =============================== the loader waves ==============================================================================
+    const int lw = wave_u - RC_NWC;                     // this loader's pieces: p = lw, lw + NLD, ... (loader 0 also brings the small operands)
     const __amdgpu_buffer_rsrc_t rs_aux = __builtin_amdgcn_make_buffer_rsrc((void*)rp.csd, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_gg = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wgg, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ff = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wff2, 0, OOB, 0x00020000);
@@ -153,10 +157,13 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
       const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_gg : (sel == 1 ? rs_ff : rs_po);
       const int ldw2 = sel == 0 ? C * 2 : (sel == 1 ? HID * 2 : 3 * C * 2);
       const int v0 = l8 * ldw2 + g16_0, v1 = l8 * ldw2 + g16_1;
+      const int vv = (lw & 1) ? v1 : v0;                // (NLD = 2, 4: the parity of a loader's pieces is its own)
 #pragma unroll
-      for (int p = 0; p < RC_UPIECES; ++p)
+      for (int pp = 0; pp < LPIECES; ++pp) {
+        const int p = pp * NLD + lw;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * RC_UNIT + p * 1024), 16,
-                                                 (p & 1) ? v1 : v0, soff + (64 * (p >> 2) + 8 * (p & 3)) * ldw2, 0, SDMI_W_AUX);
+                                                 NLD == 1 ? ((p & 1) ? v1 : v0) : vv, soff + (64 * (p >> 2) + 8 * (p & 3)) * ldw2, 0, SDMI_W_AUX);
+      }
     };
     auto issue_aux = [&](int h) {                       // {cs, d} of hidden chunk h: 5 KB into the buffer of its parity
 #pragma unroll
@@ -180,10 +187,10 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
       sel = __builtin_amdgcn_readfirstlane(kFtTab.sel[u]);
     };
     if constexpr (ABL != 2) {
-      issue_aux(0);
+      if (lw == 0) issue_aux(0);
 #pragma unroll
       for (int s = 0; s < NS - 1; ++s) {
-        if (s == 2) wait_vmcnt<LD_WAIT>();              // (5 + 40 in flight: make room in the 6-bit counter)
+        if (s == 2) wait_vmcnt<LD_WAIT>();              // (one loader: 5 + 40 in flight -- make room in the 6-bit counter)
         issue_unit(kFtTab.soff[s], kFtTab.sel[s], s);
       }
     }
@@ -194,7 +201,7 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
       if constexpr (ABL != 2) wait_vmcnt<LD_WAIT>();    // unit g has landed
       asm volatile("s_barrier" ::: "memory");           // ... and the compute waves are done with unit g - 1
       if constexpr (ABL != 2) {
-        if (d_aux != -1) {                              // (wave-uniform; 4 times per launch)
+        if (d_aux != -1 && lw == 0) {                   // (wave-uniform; 4 times per launch)
           wait_vmcnt<LD_WAIT - 5>();
           if (d_aux >= 0) issue_aux(d_aux); else prefetch_x();
         }
@@ -397,6 +404,351 @@ __global__ void __launch_bounds__(RC_NT) ff_tail_kernel(const FfTailParams rp) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+
+// =====================================================================================================================================
+// st_head_kernel: the HEAD of a SpatialTransformer as one launch (StHeadParams, common.h)
+//     t = proj_in(GroupNorm(x)) + b          attention.py:254-255 (norm, proj_in: a 1x1 conv = a dense GEMM over NHWC rows)
+//     q | k | v = norm1(t) Wqkv^T            attention.py:212, 170-176 (attn1's projections; LayerNorm folded as in igemm_epilogue)
+// Same skeleton as ff_tail_kernel (32 token rows per workgroup, five compute waves x 64 columns, loader waves streaming 20 KB weight
+// units through the LDS-DMA ring).  The flat schedule: proj_in as split-fp16 {w_hi, w_lo} unit pairs (20 units), then q, k, v
+// (10 units each).  What each stage replaces, with the same arithmetic in the same order (outputs are the same bits):
+//   prologue   = gn_apply_kernel: the strip's fp32 rows are normalised ONCE into the split-fp16 operand strips {hi, lo} in LDS
+//   proj_in    = gemm_split16_kernel (a_hi w_hi, a_lo w_hi, a_hi w_lo per k-step) + igemm_epilogue's 16-byte plain path: bias, fp32
+//                token stream to memory, fp16(gamma1 * t) into the q|k|v operand strip, LayerNorm partials per 32-column block
+//   q, k, v    = igemm_kernel + the LayerNorm-fold correction + the per-head scatter (q, k rows through the LDS slabs, v^T from the
+//                accumulator registers: four consecutive tokens per lane)
+constexpr int SH_NU = 2 * FT_BLK + 3 * FT_BLK;                           // 50 units
+struct ShUnitTab { int soff[SH_NU]; int sel[SH_NU]; };
+constexpr ShUnitTab sh_make_tab() {
+  ShUnitTab t{};
+  int u = 0;
+  for (int kt = 0; kt < FT_KT; ++kt)
+    for (int half = 0; half < 2; ++half)
+      for (int lo = 0; lo < 2; ++lo) { t.soff[u] = (32 * half) * (3 * FT_C * 2) + (64 * kt + (lo ? 2 * FT_C : 0)) * 2; t.sel[u] = 0; ++u; }
+  for (int b = 0; b < 3; ++b)
+    for (int kt = 0; kt < FT_KT; ++kt)
+      for (int half = 0; half < 2; ++half) { t.soff[u] = (FT_C * b + 32 * half) * (FT_C * 2) + kt * 128; t.sel[u] = 1; ++u; }
+  return t;
+}
+__device__ const ShUnitTab kShTab = sh_make_tab();
+
+template <int C, int NLD, int NS = RC_NS>
+__global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHeadParams rp) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C");
+  static_assert(NLD == 1 || NLD == 2, "loader waves");
+  constexpr int KT = C / 64;
+  constexpr int XBYTES = RC_ROWS * C * 2;             // one operand strip (20 KB)
+  constexpr int NU = SH_NU;
+  constexpr int RING = NS * RC_UNIT;
+  constexpr int OFF_XH = RING, OFF_XL = OFF_XH + XBYTES, OFF_XN = OFF_XL + XBYTES;
+  constexpr int OFF_GTAB = OFF_XN + XBYTES;           // {mean, rstd} of the sample's 32 GroupNorm groups
+  constexpr int OFF_LTAB = OFF_GTAB + 32 * 8;         // {mean, rstd} of the strip's rows (norm1)
+  constexpr int OFF_LNP = OFF_LTAB + RC_ROWS * 8;     // [row][C / 32] {sum, sum of squares} of the token stream's 32-column blocks
+  constexpr int LDS_TOTAL = OFF_LNP + RC_ROWS * (C / 32) * 8;
+  constexpr int LSTR = 64;                            // row pitch (floats) of the epilogue slabs: five 32 x 64 fp32 slabs = the two proj_in strips
+  static_assert(RC_NWC * 32 * LSTR * 4 <= 2 * XBYTES, "the epilogue slabs live in the (dead) proj_in operand strips");
+  constexpr int LPIECES = RC_UPIECES / NLD, LD_WAIT = LPIECES * (NS - 2);
+  static_assert(NS >= 3 && LD_WAIT + LPIECES <= 63 && LD_WAIT <= 48, "vmcnt is a 6-bit counter");
+#ifdef SDMI_RC_TIMING
+  constexpr int OFF_DBG = LDS_TOTAL;
+  static_assert(LDS_TOTAL + 1024 <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL + 1024];
+  int n_stamp = 0;
+#else
+  static_assert(LDS_TOTAL <= 160 * 1024, "LDS budget");
+  __shared__ __attribute__((aligned(16))) unsigned char smem[LDS_TOTAL];
+#endif
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+  const int m0 = blockIdx.x * RC_ROWS;
+  constexpr int OOB = (int)0x80000000;
+
+  if (wave_u >= RC_NWC) {
+    // =============================== the loader waves (see ff_tail_kernel) =========================================================
+    const int lw = wave_u - RC_NWC;
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)rp.w_in, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wqkv, 0, OOB, 0x00020000);
+    const int l8 = lane >> 3, cpos = lane & 7;
+    const int g16_0 = (cpos ^ ((l8 >> 1) & 7)) << 4, g16_1 = (cpos ^ ((4 + (l8 >> 1)) & 7)) << 4;
+    auto issue_unit = [&](int soff, int sel, int stage) {
+      const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_in : rs_qkv;
+      const int ldw2 = sel == 0 ? 3 * C * 2 : C * 2;
+      const int v0 = l8 * ldw2 + g16_0, v1 = l8 * ldw2 + g16_1;
+      const int vv = (lw & 1) ? v1 : v0;
+#pragma unroll
+      for (int pp = 0; pp < LPIECES; ++pp) {
+        const int p = pp * NLD + lw;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + stage * RC_UNIT + p * 1024), 16,
+                                                 NLD == 1 ? ((p & 1) ? v1 : v0) : vv, soff + (64 * (p >> 2) + 8 * (p & 3)) * ldw2, 0, SDMI_W_AUX);
+      }
+    };
+    auto desc = [&](int u, int& soff, int& sel) {
+      u = min(u, NU - 1);
+      soff = __builtin_amdgcn_readfirstlane(kShTab.soff[u]);
+      sel = __builtin_amdgcn_readfirstlane(kShTab.sel[u]);
+    };
+#pragma unroll
+    for (int s = 0; s < NS - 1; ++s) issue_unit(kShTab.soff[s], kShTab.sel[s], s);
+    asm volatile("s_barrier" ::: "memory");             // X0: the compute waves' GroupNorm table
+    int nxt = NS - 1, d_soff, d_sel;
+    desc(NS - 1, d_soff, d_sel);
+    for (int g = 0; g < NU; ++g) {
+      if (g == 2 * FT_BLK) asm volatile("s_barrier" ::: "memory");      // X1: proj_in's operand strips are dead (the epilogue slabs go there)
+      wait_vmcnt<LD_WAIT>();                            // unit g has landed
+      asm volatile("s_barrier" ::: "memory");           // ... and the compute waves are done with unit g - 1
+      issue_unit(d_soff, d_sel, nxt);
+      desc(g + NS, d_soff, d_sel);
+      nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    return;
+  }
+
+  // ================================= the five compute waves ==========================================================================
+#ifdef SDMI_RC_TIMING
+#define SH_STAMP() do { if (threadIdx.x == 0 && n_stamp < 128) ((long long*)(smem + OFF_DBG))[n_stamp] = (long long)__builtin_readcyclecounter(); ++n_stamp; } while (0)
+#else
+#define SH_STAMP() do { } while (0)
+#endif
+  SH_STAMP();
+  const int l31 = lane & 31, lg = lane >> 5;
+  const int bsample = m0 / rp.ntok;                    // (32 | ntok: the strip lies inside one sample)
+  const int tok0 = m0 - bsample * rp.ntok;
+  // ---- prologue: the strip's fp32 rows (thread -> rows xr + 8 i, channels 8 c8 ... 8 c8 + 7), gamma / beta of those channels, the
+  // LayerNorm-fold column terms of this lane's q | k | v columns; then the sample's GroupNorm table ----
+  const int xr = tid / 40, c8 = tid - xr * 40;
+  f32x4 xv[4][2], gv[2], bv[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float* src = rp.x + (size_t)(m0 + xr + 8 * i) * C + c8 * 8;
+    xv[i][0] = *(const f32x4*)src; xv[i][1] = *(const f32x4*)(src + 4);
+  }
+  gv[0] = *(const f32x4*)(rp.gn_gamma + c8 * 8); gv[1] = *(const f32x4*)(rp.gn_gamma + c8 * 8 + 4);
+  bv[0] = *(const f32x4*)(rp.gn_beta + c8 * 8); bv[1] = *(const f32x4*)(rp.gn_beta + c8 * 8 + 4);
+  float fcs[3][2], fdn[3][2];
+#pragma unroll
+  for (int b = 0; b < 3; ++b)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = C * b + 64 * wave + 32 * j + l31;
+      fcs[b][j] = rp.lnf_cs[n]; fdn[b][j] = rp.lnf_d[n];
+    }
+  float2* const gtab = (float2*)(smem + OFF_GTAB);
+  float2* const ltab = (float2*)(smem + OFF_LTAB);
+  if (tid < 256) {
+    // (norm.hip gn_fold: 8 consecutive lanes fold the 8 slots of a group)
+    const int g = tid >> 3, sub = tid & 7;
+    const long long* src = rp.gn_acc + ((size_t)(bsample * 32 + g) * GN_SLOTS + sub) * GN_STRIDE;
+    long long a = src[0], al = src[1], q = src[2], ql = src[3];
+#pragma unroll
+    for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {
+      a += __shfl_xor(a, o); al += __shfl_xor(al, o); q += __shfl_xor(q, o); ql += __shfl_xor(ql, o);
+    }
+    if (sub == 0) {
+      float m, r;
+      gn_mean_rstd(a, al, q, ql, (double)(C / 32) * (double)rp.ntok, rp.gn_eps, &m, &r);
+      gtab[g] = float2{m, r};
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // X0
+  {
+    // normalise (gn_apply_kernel's expression), split into hi | lo (lo_half), write the two operand strips in strip_off's layout
+    constexpr int cpg = C / 32;
+    const int c0 = c8 * 8;
+    const int g0 = c0 / cpg;
+    const int nfirst = (g0 + 1) * cpg - c0;             // channels of the octet in group g0 (cpg >= 8: at most two groups)
+    const float2 ga = gtab[g0], gb = gtab[min(g0 + 1, 31)];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = xr + 8 * i;
+      f16x8 hi, lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool second = j >= nfirst;
+        const float y = gn_apply_elem(xv[i][j >> 2][j & 3], second ? gb.x : ga.x, second ? gb.y : ga.y, gv[j >> 2][j & 3], bv[j >> 2][j & 3], 0);
+        hi[j] = (f16)y; lo[j] = (f16)(y - (float)hi[j]);
+      }
+      const int off = (c8 >> 3) * (RC_ROWS * 128) + row * 128 + (((c8 & 7) ^ ((row >> 1) & 7)) << 4);
+      *(f16x8*)(smem + OFF_XH + off) = hi;
+      *(f16x8*)(smem + OFF_XL + off) = lo;
+    }
+  }
+  SH_STAMP();
+
+  const int rsw = (l31 >> 1) & 7;
+  const int a_frag = l31 * 128, b_frag = (wave * 32 + l31) * 128;
+  int cur = 0;
+  auto unit_sync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+  auto unit_end = [&]() { cur = (cur + 1 == NS) ? 0 : cur + 1; };
+  auto frag = [&](int base, int ks) { return *(const f16x8*)(smem + base + (((ks * 2 + lg) ^ rsw) << 4)); };
+  auto zero2 = [](f32x16 (&a)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[j][r] = 0.f;
+  };
+
+  // ---- proj_in as split-fp16: per (k-tile, half) the hi unit parks its fragments, the lo unit runs the three products of every k-step
+  // in gemm_split16_kernel's order (a_hi w_hi, a_lo w_hi, a_hi w_lo) ----
+  f32x16 acc[2];
+  zero2(acc);
+  rc_static_for<KT>([&](auto ktc) {
+    constexpr int kt = decltype(ktc)::value;
+    f16x8 ah[4], al[4];
+    rc_static_for<2>([&](auto hc) {
+      constexpr int half = decltype(hc)::value;
+      f16x8 bh[4], bl[4];
+      unit_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bh[ks] = frag(cur * RC_UNIT + b_frag, ks);
+      if constexpr (half == 0) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          ah[ks] = frag(OFF_XH + kt * (RC_ROWS * 128) + a_frag, ks);
+          al[ks] = frag(OFF_XL + kt * (RC_ROWS * 128) + a_frag, ks);
+        }
+      }
+      unit_end();
+      unit_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) bl[ks] = frag(cur * RC_UNIT + b_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bh[ks], acc[half], 0, 0, 0);
+        acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[ks], bh[ks], acc[half], 0, 0, 0);
+        acc[half] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[ks], bl[ks], acc[half], 0, 0, 0);
+      }
+      unit_end();
+    });
+  });
+  SH_STAMP();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");        // X1: every wave is done reading the proj_in strips
+  // ---- proj_in epilogue (igemm_epilogue's 16-byte plain path on this wave's 32 x 64 slab): t = acc + bias -> memory (fp32), fp16(gamma1 * t)
+  // -> the q | k | v operand strip, {sum, sum of squares} per 32-column block -> the LayerNorm partial table ----
+  float* const wl = (float*)(smem + OFF_XH) + wave * (32 * LSTR);
+  const int rl = lane >> 4, c4 = (lane & 15) * 4;
+  const int nw = wave * 64;
+  {
+    const f32x4 colv = *(const f32x4*)(rp.b_in + nw + c4);
+    const f32x4 g4 = *(const f32x4*)(rp.ln_gamma + nw + c4);
+    slab_put<2, LSTR>(wl, acc, l31, lg);
+    float2* const lnp = (float2*)(smem + OFF_LNP);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = q * 4 + rl;
+      const f32x4 v = *(const f32x4*)(wl + row * LSTR + c4) + colv;
+      SDMI_ST_F32X4(rp.t, (size_t)(m0 + row) * C + nw + c4, v);
+      const f32x4 vs = v * g4;
+      *(f16x4*)(smem + OFF_XN + strip_off(row, nw + c4)) = f16x4{(f16)vs[0], (f16)vs[1], (f16)vs[2], (f16)vs[3]};
+      float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+      float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+      s1 = sum8_dpp(s1); s2 = sum8_dpp(s2);
+      if ((lane & 7) == 0) lnp[row * (C / 32) + ((nw + c4) >> 5)] = float2{s1, s2};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  }
+  SH_STAMP();
+
+  // One block of ten units = the five k-tiles of a K = C GEMM over the operand strip, two column halves each.  first(): run once behind
+  // the first unit's barrier (the LayerNorm table of the rows: every wave's partials are visible there).
+  auto block = [&](f32x16 (&a)[2], auto&& first) {
+    rc_static_for<KT>([&](auto ktc) {
+      constexpr int kt = decltype(ktc)::value;
+      f16x8 fa[4], fb[4];
+      unit_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[ks] = frag(OFF_XN + kt * (RC_ROWS * 128) + a_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], a[0], 0, 0, 0);
+      if constexpr (kt == 0) first();
+      unit_end();
+      unit_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], a[1], 0, 0, 0);
+      unit_end();
+    });
+  };
+  auto ln_table = [&]() {
+    if (tid < RC_ROWS) {                                // (lnf_finish's fold of the block partials, in block order)
+      IGemmParams lq;
+      lq.lnf_npart = C / 32; lq.lnf_eps = rp.ln_eps;
+      const float2* pp = (const float2*)(smem + OFF_LNP) + tid * (C / 32);
+      float2 pv[LNF_MAXP];
+#pragma unroll
+      for (int j = 0; j < LNF_MAXP; ++j) pv[j] = j < C / 32 ? pp[j] : float2{0.f, 0.f};
+      float mu, rs_;
+      lnf_finish(lq, pv, &mu, &rs_);
+      ltab[tid] = float2{mu, rs_};
+    }
+  };
+  auto nothing = []() {};
+  // LayerNorm-fold correction of a finished accumulator pair (igemm_epilogue's expression)
+  auto fold = [&](f32x16 (&a)[2], const float (&cs_)[2], const float (&dn_)[2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float2 mr = ltab[(r & 3) + 8 * (r >> 2) + 4 * lg];
+        a[j][r] = fmaf(mr.y, a[j][r] - mr.x * cs_[j], dn_[j]);
+      }
+  };
+  // q / k: [B * heads][ntok][dh] rows through the wave's LDS slab -- a lane stores 4 consecutive dd of a token
+  auto rows_out = [&](f32x16 (&a)[2], f16* dst) {
+    slab_put<2, LSTR>(wl, a, l31, lg);
+    const int n = nw + c4;
+    const int head = n / rp.dh, dd = n - head * rp.dh;
+    f16* const base = dst + (((size_t)bsample * rp.heads + head) * rp.ntok + tok0) * rp.dh + dd;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int row = q * 4 + rl;
+      const f32x4 v = *(const f32x4*)(wl + row * LSTR + c4);
+      SDMI_ST(f16x4, base + (size_t)row * rp.dh, (f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}));
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  zero2(acc);
+  block(acc, ln_table);                                 // q
+  SH_STAMP();
+  fold(acc, fcs[0], fdn[0]);
+  rows_out(acc, rp.q);
+  SH_STAMP();
+  zero2(acc);
+  block(acc, nothing);                                  // k
+  SH_STAMP();
+  fold(acc, fcs[1], fdn[1]);
+  rows_out(acc, rp.k);
+  SH_STAMP();
+  zero2(acc);
+  block(acc, nothing);                                  // v
+  SH_STAMP();
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (pairs with the loaders' last barrier)
+  fold(acc, fcs[2], fdn[2]);
+  // v^T: [B * heads][dh][ntok_pad] straight from the accumulator registers (lane = column, registers 4 r4 ... 4 r4 + 3 = 4 consecutive tokens)
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int n = nw + j * 32 + l31;
+    const int head = n / rp.dh, dd = n - head * rp.dh;
+    f16* const base = rp.vt + (((size_t)bsample * rp.heads + head) * rp.dh + dd) * rp.ntok_pad + tok0 + 4 * lg;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4)
+      *(f16x4*)(base + 8 * r4) = f16x4{(f16)acc[j][r4 * 4 + 0], (f16)acc[j][r4 * 4 + 1], (f16)acc[j][r4 * 4 + 2], (f16)acc[j][r4 * 4 + 3]};
+  }
+#ifdef SDMI_RC_TIMING
+  SH_STAMP();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  if (rp.dbg && tid < 64) rp.dbg[(size_t)blockIdx.x * 128 + tid] = tid < n_stamp ? ((const long long*)(smem + OFF_DBG))[tid] : 0;
+#endif
+#endif  // __HIP_DEVICE_COMPILE__
+}
+
 }  // namespace
 
 // May the tail of a SpatialTransformer (GEGLU -> FF-out -> proj_out) run as one ff_tail_kernel launch?  C channels, M token rows,
@@ -426,7 +778,7 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   FfTailParams q = p;
   q.epi.splitk = 1; q.epi.splitk_fused = 0; q.epi.slab_tiled = 0;
   q.epi.epi_vec = epi_vec_ok(e);
-  q.epi.magic_hw = div_magic(e.Hout * e.Wout);
+  q.epi.magic_hw = div_magic_hw(e.Hout * e.Wout);
   q.epi.magic_w = div_magic(e.Wout);
   for (int t = 0; t < e.gn_n; ++t) q.epi.gn_magic[t] = div_magic(e.gn_cpg[t]);
   const double M = e.M;
@@ -434,20 +786,52 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   ProfScope ps("ff_tail_32x320w5", 2.0 * M * (8.0 * C * C + 4.0 * C * C + (double)C * C),
                M * C * (2.0 + 4.0 + 4.0 + 4.0 + (e.out_f16 ? 2.0 : 0.0)) + 13.0 * C * C * 2.0, stream,
                2.0 * M * (8.0 * C * C + 4.0 * C * C + 3.0 * C * C));
-  const dim3 grid(e.M / RC_ROWS), blk(RC_NT);
+  const dim3 grid(e.M / RC_ROWS);
+  const int nld_env = env_int("SDMI_FF_TAIL_LD", RC_NLD_DEFAULT);      // loader waves (read per launch: A/B)
 #ifdef SDMI_RC_TIMING
   q.dbg = g_rc_dbg;
-  switch (g_rc_abl) {
-    case 1: hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, blk, 0, stream, q); break;
-    case 2: hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, blk, 0, stream, q); break;
-    case 3: hipLaunchKernelGGL((ff_tail_kernel<320, 3>), grid, blk, 0, stream, q); break;
-    case 10: hipLaunchKernelGGL((ff_tail_kernel<320, 0, 3>), grid, blk, 0, stream, q); break;     // ring depth 3
-    case 11: hipLaunchKernelGGL((ff_tail_kernel<320, 1, 3>), grid, blk, 0, stream, q); break;
-    default: hipLaunchKernelGGL((ff_tail_kernel<320, 0>), grid, blk, 0, stream, q); break;
-  }
+  const int abl = g_rc_abl % 10, nld = g_rc_abl >= 10 ? g_rc_abl / 10 : nld_env;      // 10 a + x: ablation x with a loader waves
+#define RC_LAUNCH(NLD, ABL) hipLaunchKernelGGL((ff_tail_kernel<320, NLD, ABL>), grid, dim3(RC_NTC + 64 * NLD), 0, stream, q)
+#define RC_ABL(NLD) switch (abl) { case 1: RC_LAUNCH(NLD, 1); break; case 2: RC_LAUNCH(NLD, 2); break; case 3: RC_LAUNCH(NLD, 3); break; default: RC_LAUNCH(NLD, 0); break; }
+  if (nld == 1) { RC_ABL(1) } else if (nld == 4) { RC_ABL(4) } else { RC_ABL(2) }
 #else
-  hipLaunchKernelGGL((ff_tail_kernel<320>), grid, blk, 0, stream, q);
+  if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else if (nld_env == 4) hipLaunchKernelGGL((ff_tail_kernel<320, 4>), grid, dim3(RC_NTC + 256), 0, stream, q);
+  else hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
 #endif
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+
+// May the head of a SpatialTransformer (GroupNorm-apply -> proj_in -> q | k | v) run as one st_head_kernel launch?
+bool st_head_supported(int C, int M, int ntok, int ntok_pad, int heads, int dh) {
+  return C == 320 && M % RC_ROWS == 0 && ntok % RC_ROWS == 0 && M % ntok == 0 && heads * dh == C && dh % 4 == 0 && ntok % 4 == 0 &&
+         ntok_pad % 4 == 0 && ntok_pad >= ntok && (int64_t)M * C * 4 < ((int64_t)1 << 31);
+}
+
+#ifdef SDMI_RC_TIMING
+static long long* g_sh_dbg = nullptr;
+extern "C" int sdmi_k_st_head_dbg(void* stamps) { g_sh_dbg = (long long*)stamps; return 0; }
+#endif
+
+int launch_st_head(const StHeadParams& p, hipStream_t stream) {
+  SDMI_CHECK(st_head_supported(p.C, p.M, p.ntok, p.ntok_pad, p.heads, p.dh), "st_head: C = 320, rows (per sample) multiples of 32, heads * dh = C, dh % 4 = 0");
+  SDMI_CHECK(p.x && p.gn_acc && p.gn_gamma && p.gn_beta && p.w_in && p.b_in && p.t && p.ln_gamma && p.wqkv && p.lnf_cs && p.lnf_d && p.q && p.k && p.vt,
+             "st_head: null operand");
+  SDMI_CHECK(p.B * p.ntok == p.M, "st_head: M = B * ntok");
+  const double M = p.M, C = p.C;
+  // algorithmic work of the reference ops (proj_in once, q | k | v), one read of x and the weights, t / q / k / v written once
+  ProfScope ps("st_head_32x320w5", 2.0 * M * (C * C + 3.0 * C * C), M * C * (4.0 + 4.0 + 3 * 2.0) + 4.0 * C * C * 2.0, stream,
+               2.0 * M * (3.0 * C * C + 3.0 * C * C));
+  StHeadParams q = p;
+  const dim3 grid(p.M / RC_ROWS);
+  const int nld = env_int("SDMI_FF_TAIL_LD", RC_NLD_DEFAULT);          // loader waves (read per launch: A/B)
+#ifdef SDMI_RC_TIMING
+  q.dbg = g_sh_dbg;
+#endif
+  if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else hipLaunchKernelGGL((st_head_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

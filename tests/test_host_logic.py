@@ -530,3 +530,29 @@ def test_register_order_slab_layout_model():
             for n in range(0, N, 3):
                 seen.add(gemm_index(m, n, BM, BN, WM, WN, tiles_n))
         assert len(seen) == len(range(0, M, 5)) * len(range(0, N, 3)) and max(seen) < M * N
+
+
+def test_row_to_sample_magic_division_model():
+    """csrc/igemm_dev.h fast_div_hw / div_magic_hw (the implicit GEMM's row -> sample split m / (Hout*Wout)): the 2^48 multiply-shift
+    form is exact for every row index of every supported batch, and the 2^40 form it replaced was NOT at four 768 x 768 first-stage
+    maps (m * d >= 2^40: the last pixel of the last sample came out as sample 4 -- tests/test_vae_gpu.py::test_vae_decode_outputs_beyond_2_gb)."""
+    def magic(d, s):
+        return ((1 << s) + d - 1) // d
+
+    def fdiv(m, mg, s):
+        prod = m * mg
+        assert prod < (1 << 64), 'the product must fit the 64-bit multiply'
+        return prod >> s
+    for hw in (64, 77, 256, 1024, 4096, 9216, 96 * 96 * 64, 768 * 768, 1024 * 1024):
+        for B in (1, 2, 3, 4, 8):
+            M = B * hw
+            if M >= 1 << 31:
+                continue
+            mg = magic(hw, 48)
+            ms = set()
+            for b in range(B):
+                ms.update((b * hw, b * hw + 1, b * hw + hw // 2, (b + 1) * hw - 2, (b + 1) * hw - 1))
+            for m in ms:
+                assert fdiv(m, mg, 48) == m // hw, (hw, B, m)
+    hw, m = 768 * 768, 4 * 768 * 768 - 1
+    assert fdiv(m, magic(hw, 40), 40) == 4 and m // hw == 3       # the bug the 2^48 form fixes

@@ -31,7 +31,7 @@ def one():
 
 
 NAMES = ['P0(0)', 'P1(0)', 'P0(1)', 'P1(1)', 'FF(0)', 'P0(2)', 'P1(2)', 'FF(1)', 'P0(3)', 'P1(3)', 'FF(2)', 'FF(3)']
-for abl in (0, 1, 2, 3, 10, 11):      # 1x: ring depth 3 (x = the ablation)
+for abl in (20, 21, 22, 23, 10, 11, 40, 41):      # 10 a + x: ablation x with a loader waves
     dbg_fn(stamps.data_ptr(), abl)
     for _ in range(5):
         one()
@@ -50,7 +50,7 @@ for abl in (0, 1, 2, 3, 10, 11):      # 1x: ring depth 3 (x = the ablation)
     print(f'ABL {abl}: {us:7.1f} us per launch | workgroup cycles mean {tot.mean():9.0f} max {tot.max():9.0f} | prologue {mean[0]:6.0f} | '
           f'FF-out epilogue {mean[61]:6.0f} | proj_out {mean[62:67].sum() / 20:5.0f} cyc/unit | drain {mean[67]:6.0f} | final epilogue {mean[68]:6.0f}', flush=True)
     print('    cycles per unit by block: ' + '  '.join(f'{n} {mean[1 + 5 * b:6 + 5 * b].sum() / 10:4.0f}' for b, n in enumerate(NAMES)), flush=True)
-    if abl == 0:
+    if abl % 10 == 0:
         print('    P1(1) per k-tile step (2 units):', ' '.join(f'{v:5.0f}' for v in mean[16:21]), '| FF(0):', ' '.join(f'{v:5.0f}' for v in mean[21:26]), flush=True)
         print(f'    per-workgroup total cycles: min {tot.min():.0f} p50 {tot.median():.0f} max {tot.max():.0f}', flush=True)
 dbg_fn(None, 0)
