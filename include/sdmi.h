@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 12
+#define SDMI_ABI_VERSION 13
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -254,6 +254,17 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
  * hidden chunk of C: [4][cs of 2C packed columns | d of the same 2C]; wgg [8C][C], wff2 [C][4C] fp16, bff2 [C], t [M][C] fp32. */
 int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const float* lnp, float ln_eps, const float* csd,
                    const void* wgg_f16, const void* wff2_f16, const float* bff2, const float* t, void* stream);
+/* GroupNorm-apply -> proj_in -> q | k | v of a SpatialTransformer as ONE launch (ABI 13; csrc/rowchain.hip; ldm/modules/attention.py:254-256,
+ * 212, 170-176): t = proj_in(GroupNorm(x)) + b_in (fp32 [M][C], M = B * ntok), q | k | v = norm1(t) Wqkv^T scattered per head
+ * (q, k: [B * heads][ntok][dh] fp16, vt: [B * heads][dh][ntok_pad] fp16) for C = 320 channels, a workgroup per 32 token rows.
+ * x [M][C] fp32; gn_ws: sdmi_k_groupnorm_ws_floats(B, ntok) floats of scratch (the statistics are computed here, as sdmi_k_groupnorm does);
+ * w_in3 = sdmi_k_pack_split3(proj_in weight) [C][3C]; ln_gamma = norm1 weight; wqkv [3C][C] fp16 (to_q | to_k | to_v rows);
+ * lnf_cs / lnf_d [3C] = sdmi_k_ln_fold_prep(wqkv, norm1 weight, norm1 bias).  Same arithmetic, in the same order, as sdmi_k_groupnorm
+ * (f16 + lo outputs) -> sdmi_k_igemm (split16, f16_scale, lnp_out) -> sdmi_k_igemm (mode 2, lnf_*): the outputs are the same bits. */
+int sdmi_k_st_head(const float* x, float* gn_ws, int64_t gn_ws_floats, const float* gn_gamma, const float* gn_beta, float gn_eps,
+                   const void* w_in3, const float* b_in, float* t, const float* ln_gamma, float ln_eps, const void* wqkv_f16,
+                   const float* lnf_cs, const float* lnf_d, void* q, void* k, void* vt, int B, int ntok, int ntok_pad, int heads, int dh,
+                   int C, void* stream);
 /* cs[n] = sum_k gamma[k] * w[n][k], d[n] = sum_k beta[k] * w[n][k] (+ bias[n]) over the PACKED fp16 weights w [N][ldw]
  * (first K columns of a row): the column terms of a GEMM that folds LayerNorm(gamma, beta) of its input rows */
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,

@@ -278,6 +278,23 @@ int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const fl
   q.bff2 = bff2; q.t = t; q.wpo = (const f16*)proj_out->w;
   return launch_ff_tail(q, (hipStream_t)stream);
 }
+int sdmi_k_st_head(const float* x, float* gn_ws, int64_t gn_ws_floats, const float* gn_gamma, const float* gn_beta, float gn_eps,
+                   const void* w_in3, const float* b_in, float* t, const float* ln_gamma, float ln_eps, const void* wqkv_f16,
+                   const float* lnf_cs, const float* lnf_d, void* q, void* k, void* vt, int B, int ntok, int ntok_pad, int heads, int dh,
+                   int C, void* stream) {
+  SDMI_CHECK(x && gn_ws && gn_gamma && gn_beta, "st_head: null argument");
+  SDMI_CHECK(gn_ws_floats >= gn_acc_words(B) * 2, "groupnorm workspace too small");
+  SDMI_HIP_OK(hipMemsetAsync(gn_ws, 0, gn_acc_words(B) * sizeof(long long), (hipStream_t)stream));
+  GroupNormParams g;
+  g.x0 = x; g.c0 = C; g.B = B; g.HW = ntok; g.gamma = gn_gamma; g.beta = gn_beta; g.eps = gn_eps; g.stats_only = 1; g.acc = (long long*)gn_ws;
+  if (launch_groupnorm(g, (hipStream_t)stream)) return -1;
+  StHeadParams p;
+  p.x = x; p.gn_acc = (const long long*)gn_ws; p.gn_gamma = gn_gamma; p.gn_beta = gn_beta; p.gn_eps = gn_eps;
+  p.w_in = (const f16*)w_in3; p.b_in = b_in; p.t = t; p.ln_gamma = ln_gamma; p.ln_eps = ln_eps; p.wqkv = (const f16*)wqkv_f16;
+  p.lnf_cs = lnf_cs; p.lnf_d = lnf_d; p.q = (f16*)q; p.k = (f16*)k; p.vt = (f16*)vt;
+  p.M = B * ntok; p.B = B; p.ntok = ntok; p.ntok_pad = ntok_pad; p.heads = heads; p.dh = dh; p.C = C;
+  return launch_st_head(p, (hipStream_t)stream);
+}
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,
                         float* cs, float* d, void* stream) {
   return launch_ln_fold_prep((const f16*)w_f16, N, K, ldw, gamma, beta, bias, cs, d, (hipStream_t)stream);

@@ -460,6 +460,7 @@ struct Fwd : FwdBase {
   UNet* u; int Lctx;
   bool ln_fold_on = false;      // this call folds LayerNorms into their consuming GEMMs (UNet::ln_fold_; read per call: A/B knobs)
   bool ff_tail_on = false;      // ... and runs SpatialTransformer tails as row-strip chain launches (UNet::ff_tail_; SDMI_FF_TAIL, read per call)
+  bool st_head_on = false;      // ... and SpatialTransformer heads (UNet::st_head_; SDMI_ST_HEAD, read per call)
   // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
   bool fuse_ctx_q = false;
@@ -580,8 +581,12 @@ struct Fwd : FwdBase {
     pin.M = M; pin.N = C; pin.K = C; pin.ksize = 1; pin.Hout = N; pin.Wout = 1; pin.B = B;
     const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 1280 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
     const bool gn_in_gemm = gn_proj_fold && fold_ln && precise_1x1 && M >= 512 && split16_gn_supported(pin);
+    // the head of the SpatialTransformer (GroupNorm-apply -> proj_in -> q | k | v of the first transformer block) as one row-strip chain
+    // launch (rowchain.hip st_head_kernel; UNet::st_head_): LayerNorm fold on, split-fp16 proj_in, C = 320
+    const bool chain_head = st_head_on && fold_ln && precise_1x1 && !gn_in_gemm && L.tb[0].lnf[0] != nullptr &&
+                            st_head_supported(C, M, N, Np, L.heads, L.dh) && dense1x1(nullptr, nullptr, M, C, L.w16[0], C, N).split16;
     long long* gn_stats = nullptr;
-    if (gn_in_gemm) gn_stats = groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
+    if (gn_in_gemm || chain_head) gn_stats = groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
     else groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
     float* t = S<float>((size_t)M * C);
     f16* ln = S<f16>((size_t)M * C);
@@ -603,7 +608,19 @@ struct Fwd : FwdBase {
       if (!fold_ln) return;
       p.lnf_part = lnp; p.lnf_npart = C / 32; p.lnf_eps = 1e-5f; p.lnf_cs = cs; p.lnf_d = dn; p.bias = nullptr;
     };
-    if (gn_in_gemm) {
+    if (chain_head) {
+      TBlock& T = L.tb[0];
+      StHeadParams h;
+      h.x = x.p; h.gn_acc = gn_stats; h.gn_gamma = L.f32[0]; h.gn_beta = L.f32[1]; h.gn_eps = 1e-6f;
+      h.w_in = L.w16[0]; h.b_in = L.f32[2]; h.t = t; h.ln_gamma = T.ln[0]; h.ln_eps = 1e-5f;
+      h.wqkv = T.wqkv; h.lnf_cs = T.lnf[0]; h.lnf_d = T.lnf[1]; h.q = q; h.k = k; h.vt = vt;
+      h.M = M; h.B = B; h.ntok = N; h.ntok_pad = Np; h.heads = L.heads; h.dh = L.dh; h.C = C;
+      if (!dry && !rc && Np != N) {
+        hipError_t e = hipMemsetAsync(vt, 0, (size_t)B * C * Np * sizeof(f16), s);
+        if (e != hipSuccess) ok(fail(std::string("hipMemsetAsync: ") + hipGetErrorString(e)));
+      }
+      if (!dry && !rc) ok(launch_st_head(h, s));
+    } else if (gn_in_gemm) {
       IGemmParams p = dense(nullptr, M, C, L.w16[0], C, N);
       p.xf0 = x.p; p.gn_in_acc = gn_stats; p.gn_in_gamma = L.f32[0]; p.gn_in_beta = L.f32[1]; p.gn_in_eps = 1e-6f; p.gn_in_silu = 0;
       p.ldw = 3 * C; p.splitk = 1;
@@ -625,7 +642,7 @@ struct Fwd : FwdBase {
     for (int d = 0; d < depth; ++d) {
       TBlock& T = L.tb[d];
       // x = attn1(norm1(x)) + x                                   attention.py:212
-      {
+      if (!(chain_head && d == 0)) {       // (the chain launch above has written q, k, v^T of the first block)
         IGemmParams p = dense(ln, M, C, T.wqkv, 3 * C, N);
         p.mode = EPI_HEADS; p.seg_dst[0] = q; p.seg_dst[1] = k; p.seg_dst[2] = vt;
         p.seg_kind[0] = 0; p.seg_kind[1] = 0; p.seg_kind[2] = 1;
@@ -858,6 +875,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     f.ln_fold_on = (e_fold ? atoi(e_fold) != 0 : ln_fold_) && !(e_vec && atoi(e_vec) == 0);
     const char* e_ff = getenv("SDMI_FF_TAIL");
     f.ff_tail_on = e_ff ? atoi(e_ff) != 0 : ff_tail_;
+    const char* e_sh = getenv("SDMI_ST_HEAD");
+    f.st_head_on = e_sh ? atoi(e_sh) != 0 : st_head_;
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);

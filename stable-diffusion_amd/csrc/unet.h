@@ -324,6 +324,9 @@ class UNet {
   // SpatialTransformer tails (GEGLU -> FF-out -> proj_out) as one row-strip chain launch where the geometry fits (the 64 x 64 level of
   // SD v1: C = 320); rides on the LayerNorm fold.  SDMI_FF_TAIL=0 restores the three launches (bit-identical outputs; A/B).
   bool ff_tail_ = true;
+  // ... and SpatialTransformer heads (GroupNorm-apply -> proj_in -> q | k | v of the first transformer block) likewise.  SDMI_ST_HEAD=0
+  // restores the three launches (bit-identical outputs; A/B).
+  bool st_head_ = true;
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
   std::vector<Layer> middle_;

@@ -113,6 +113,19 @@ def ff_tail(ln16, part, eps, csd, wgg, wff2, bff2, t, wpo3, bpo, x_in, out_f32, 
                                           wff2.data_ptr(), bff2.data_ptr(), t.data_ptr(), _s()))
 
 
+def st_head(x, gn_gamma, gn_beta, gn_eps, w_in3, b_in, t, ln_gamma, ln_eps, wqkv, cs, dn, q, k, vt, B, ntok, heads, dh):
+    """GroupNorm-apply -> proj_in -> q | k | v as one launch (sdmi_k_st_head).  x [B * ntok, C] fp32; w_in3 = pack_split3(proj_in weight);
+    wqkv [3C, C] fp16; (cs, dn) = ln_fold_prep(wqkv, C, norm1 weight, norm1 bias); t [M, C] fp32, q / k [B * heads, ntok, dh],
+    vt [B * heads, dh, ntok_pad] fp16 are written."""
+    C_ = x.shape[1]
+    n = _lib.load().sdmi_k_groupnorm_ws_floats(B, ntok)
+    ws = torch.empty((n,), dtype=torch.float32, device=x.device)
+    _lib.check(_lib.load().sdmi_k_st_head(x.data_ptr(), ws.data_ptr(), n, gn_gamma.data_ptr(), gn_beta.data_ptr(), float(gn_eps),
+                                          w_in3.data_ptr(), b_in.data_ptr(), t.data_ptr(), ln_gamma.data_ptr(), float(ln_eps),
+                                          wqkv.data_ptr(), cs.data_ptr(), dn.data_ptr(), q.data_ptr(), k.data_ptr(), vt.data_ptr(),
+                                          B, ntok, vt.shape[2], heads, dh, C_, _s()))
+
+
 _CNT = {}
 
 

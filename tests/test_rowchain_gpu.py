@@ -2,7 +2,10 @@
 
 ff_tail: GEGLU -> FF-out -> proj_out of a SpatialTransformer (ldm/modules/attention.py:58-64,214,258-261) as ONE launch.  The fused
 kernel performs the same MFMA accumulations in the same order as the three unsplit launches, so its outputs are compared bit for
-bit; the GroupNorm statistics are sums of differently grouped fp32 partials (fixed-point accumulated) and are compared to 1e-6."""
+bit; the GroupNorm statistics are sums of differently grouped fp32 partials (fixed-point accumulated) and are compared to 1e-6.
+
+st_head: GroupNorm -> proj_in -> (norm1) q | k | v (attention.py:254-256, 212, 170-176) as ONE launch, bit for bit against the
+GroupNorm-apply + split-fp16 GEMM + q|k|v GEMM launches, and against fp32 torch."""
 import math
 
 import pytest
@@ -126,3 +129,87 @@ def test_ff_tail_repeats_bit_identically_next_to_other_work():
         out = torch.full((c['M'], c['C']), float('nan'), device=DEV)
         K.ff_tail(c['ln16'], c['part'], 1e-5, c['csd'], c['wp'], c['wff2'], c['bff2'], c['t'], c['wpo3'], c['bpo'], c['x_in'], out, 2, 4096)
         assert torch.equal(out, out0), (i, float((out - out0).abs().max()))
+
+
+def _st_head_case(B, ntok, seed, heads=8):
+    g = _g(seed)
+    C_ = 320
+    M = B * ntok
+    d = lambda t: t.to(DEV)
+    x = torch.randn(B, ntok, C_, generator=g) * 1.7 + 0.4 * torch.randn(1, 1, C_, generator=g)
+    gn_g = 1 + 0.2 * torch.randn(C_, generator=g); gn_b = 0.1 * torch.randn(C_, generator=g)
+    w_in = torch.randn(C_, C_, generator=g) / math.sqrt(C_); b_in = torch.randn(C_, generator=g) * 0.1
+    ln_g = 1 + 0.2 * torch.randn(C_, generator=g); ln_b = 0.1 * torch.randn(C_, generator=g)
+    wqkv = (torch.randn(3 * C_, C_, generator=g) / math.sqrt(C_))
+    return dict(B=B, ntok=ntok, M=M, C=C_, heads=heads, dh=C_ // heads, x=x, gn_g=gn_g, gn_b=gn_b, w_in=w_in, b_in=b_in, ln_g=ln_g, ln_b=ln_b,
+                wqkv=wqkv, dx=d(x), dgn_g=d(gn_g), dgn_b=d(gn_b), w_in3=K.pack_split3(d(w_in)), db_in=d(b_in), dln_g=d(ln_g), dln_b=d(ln_b),
+                wqkv16=d(wqkv).half().contiguous())
+
+
+def _st_head_outputs(c):
+    B, ntok, M, C_, heads, dh = c['B'], c['ntok'], c['M'], c['C'], c['heads'], c['dh']
+    ntp = (ntok + 7) // 8 * 8
+    t = torch.full((M, C_), float('nan'), device=DEV)
+    q = torch.full((B * heads, ntok, dh), float('nan'), dtype=torch.float16, device=DEV)
+    k = torch.full_like(q, float('nan'))
+    vt = torch.zeros((B * heads, dh, ntp), dtype=torch.float16, device=DEV)
+    return t, q, k, vt
+
+
+def _st_head_launches(c):
+    """the three launches of the multi-launch path (unet.cpp attn_block): GroupNorm-apply -> proj_in (split-fp16) -> q | k | v"""
+    B, ntok, M, C_, heads, dh = c['B'], c['ntok'], c['M'], c['C'], c['heads'], c['dh']
+    o = K.groupnorm(c['dx'], None, c['dgn_g'], c['dgn_b'], 1e-6, 0, want=('f16', 'lo'))
+    t, q, k, vt = _st_head_outputs(c)
+    ln16 = torch.empty(M, C_, dtype=torch.float16, device=DEV)
+    part = torch.full((C_ // 32, M, 2), float('nan'), device=DEV)
+    K.igemm(o['f16'].view(M, C_), c['w_in3'], C_, B, ntok, 1, ntok, 1, a1=o['lo'].view(M, C_), bias=c['db_in'], out_f32=t, out_f16=ln16,
+            f16_scale=c['dln_g'], lnp_out=part, split16=True)
+    cs, dn = K.ln_fold_prep(c['wqkv16'], C_, c['dln_g'], c['dln_b'])
+    K.igemm(ln16, c['wqkv16'], 3 * C_, B, ntok, 1, ntok, 1, mode=2, lnf=(part, 1e-5, cs, dn),
+            heads=dict(segs=[(q, 0), (k, 0), (vt, 1)], heads=heads, dh=dh, ntok=ntok, ntok_pad=vt.shape[2], segC=C_))
+    return t, q, k, vt, cs, dn
+
+
+@pytest.mark.parametrize('B,ntok', [(2, 4096), (1, 64), (3, 128), (2, 9216)])
+def test_st_head_is_bit_identical_to_the_three_launches(B, ntok):
+    c = _st_head_case(B, ntok, 4321 + ntok)
+    M, C_, heads, dh = c['M'], c['C'], c['heads'], c['dh']
+    t0, q0, k0, vt0, cs, dn = _st_head_launches(c)
+    t, q, k, vt = _st_head_outputs(c)
+    K.st_head(c['dx'].view(M, C_), c['dgn_g'], c['dgn_b'], 1e-6, c['w_in3'], c['db_in'], t, c['dln_g'], 1e-5, c['wqkv16'], cs, dn, q, k, vt,
+              B, ntok, heads, dh)
+    torch.cuda.synchronize()
+    # fp32 torch (sanity of the math)
+    xn = F.group_norm(c['x'].transpose(1, 2), 32, c['gn_g'], c['gn_b'], 1e-6).transpose(1, 2).reshape(M, C_)
+    t_ref = xn @ c['w_in'].t() + c['b_in']
+    qkv = F.layer_norm(t_ref, (C_,), c['ln_g'], c['ln_b'], 1e-5) @ c['wqkv'].half().float().t()
+    q_ref = qkv[:, :C_].reshape(B, ntok, heads, dh).permute(0, 2, 1, 3).reshape(B * heads, ntok, dh)
+    k_ref = qkv[:, C_:2 * C_].reshape(B, ntok, heads, dh).permute(0, 2, 1, 3).reshape(B * heads, ntok, dh)
+    v_ref = qkv[:, 2 * C_:].reshape(B, ntok, heads, dh).permute(0, 2, 3, 1).reshape(B * heads, dh, ntok)
+    assert K.report(f'st_head t B{B} n{ntok}', t, t_ref, 2e-3) < 2e-3
+    assert K.report(f'st_head q B{B} n{ntok}', q.float(), q_ref, 2e-2) < 2e-2
+    assert K.report(f'st_head k B{B} n{ntok}', k.float(), k_ref, 2e-2) < 2e-2
+    assert K.report(f'st_head vt B{B} n{ntok}', vt[:, :, :ntok].float(), v_ref, 2e-2) < 2e-2
+    same = [torch.equal(a, b) for a, b in ((t, t0), (q, q0), (k, k0), (vt, vt0))]
+    print(f'[st_head vs launches] t / q / k / vt equal: {same}; max diffs '
+          f'{[float((a.float() - b.float()).abs().max()) for a, b in ((t, t0), (q, q0), (k, k0), (vt, vt0))]}', flush=True)
+    assert all(same)
+
+
+def test_st_head_repeats_bit_identically_next_to_other_work():
+    c = _st_head_case(2, 4096, 11)
+    M, C_, heads, dh = c['M'], c['C'], c['heads'], c['dh']
+    cs, dn = K.ln_fold_prep(c['wqkv16'], C_, c['dln_g'], c['dln_b'])
+    ref = None
+    junk = torch.empty(96 << 20, device=DEV)
+    for i in range(30):
+        if i % 2:
+            junk.fill_(float(i))
+        t, q, k, vt = _st_head_outputs(c)
+        K.st_head(c['dx'].view(M, C_), c['dgn_g'], c['dgn_b'], 1e-6, c['w_in3'], c['db_in'], t, c['dln_g'], 1e-5, c['wqkv16'], cs, dn, q, k, vt,
+                  2, 4096, heads, dh)
+        if ref is None:
+            ref = (t, q, k, vt)
+        else:
+            assert all(torch.equal(a, b) for a, b in zip((t, q, k, vt), ref)), i
