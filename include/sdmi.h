@@ -265,6 +265,12 @@ int sdmi_k_st_head(const float* x, float* gn_ws, int64_t gn_ws_floats, const flo
                    const void* w_in3, const float* b_in, float* t, const float* ln_gamma, float ln_eps, const void* wqkv_f16,
                    const float* lnf_cs, const float* lnf_d, void* q, void* k, void* vt, int B, int ntok, int ntok_pad, int heads, int dh,
                    int C, void* stream);
+/* The middle of a BasicTransformerBlock as ONE launch (ABI 13; same kernel; attention.py:212-213, 170, 191-192): t += a Wo^T + bo in place
+ * (a [M][C] fp16 = the self-attention output, wo [C][C] fp16, t [M][C] fp32), q = norm2(t) Wq^T scattered per head ([B * heads][ntok][dh] fp16);
+ * ln_gamma = norm2 weight, lnf_cs / lnf_d [C] = sdmi_k_ln_fold_prep(wq, norm2 weight, norm2 bias).  The same bits as sdmi_k_igemm (bias,
+ * residual = t, out_f32 = t, f16_scale, lnp_out) -> sdmi_k_igemm (mode 2, lnf_*). */
+int sdmi_k_st_mid(const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma, float ln_eps, const void* wq_f16,
+                  const float* lnf_cs, const float* lnf_d, void* q, int B, int ntok, int heads, int dh, int C, void* stream);
 /* cs[n] = sum_k gamma[k] * w[n][k], d[n] = sum_k beta[k] * w[n][k] (+ bias[n]) over the PACKED fp16 weights w [N][ldw]
  * (first K columns of a row): the column terms of a GEMM that folds LayerNorm(gamma, beta) of its input rows */
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,

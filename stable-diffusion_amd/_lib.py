@@ -93,6 +93,8 @@ _SIGS = {
     'sdmi_clip_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
     'sdmi_k_igemm': (C.c_int, [C.POINTER(IGemmDesc), c_ptr]),
     'sdmi_k_ff_tail': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'sdmi_k_st_mid': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
+                                C.c_int, c_ptr]),
     'sdmi_k_st_head': (C.c_int, [c_ptr, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr,
                                  c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_attention_causal': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,

@@ -306,6 +306,7 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream);
 // projections) as ONE launch instead of GroupNorm-apply, the split-fp16 proj_in GEMM and the q|k|v GEMM.  Same arithmetic in the same order as
 // those launches (the outputs are the same bits).
 struct StHeadParams {
+  const f16* a16 = nullptr;        // (launch_st_mid only) [M][C] fp16: the self-attention output rows, operand of the out-projection
   const float* x = nullptr;        // [M][C] fp32: the SpatialTransformer's input (NHWC rows)
   const long long* gn_acc = nullptr;   // GroupNorm statistics accumulators of x (GroupNormParams::acc, complete before the launch)
   const float* gn_gamma = nullptr; const float* gn_beta = nullptr; float gn_eps = 1e-6f;
@@ -325,6 +326,9 @@ struct StHeadParams {
 };
 bool st_head_supported(int C, int M, int ntok, int ntok_pad, int heads, int dh);
 int launch_st_head(const StHeadParams& p, hipStream_t stream);
+// ... and the MIDDLE of a BasicTransformerBlock on the same kernel: t += a16 Wo^T + b_in in place (w_in = Wo [C][C] plain fp16), q = norm2(t) Wq^T
+// (ln_gamma = norm2 weight, wqkv = Wq [C][C], lnf_cs / lnf_d [C]; k / vt / x / gn_* unused)     attention.py:212-213, 170, 191-192
+int launch_st_mid(const StHeadParams& p, hipStream_t stream);
 
 // Flash attention over per-head layouts produced by EPI_HEADS
 struct AttnParams {

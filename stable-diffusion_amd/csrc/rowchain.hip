@@ -45,7 +45,8 @@ namespace {
 constexpr int RC_ROWS = 32;                    // token rows per workgroup
 constexpr int RC_NWC = 5;                      // compute waves (threads 0 .. 319)
 constexpr int RC_NTC = RC_NWC * 64;
-constexpr int RC_NLD_MAX = 4;                  // loader waves: 1, 2 or 4 (template argument NLD; wave RC_NWC + l issues pieces p = l mod NLD)
+// loader waves: 1 or 2 (template argument NLD; wave RC_NWC + l issues pieces p = l mod NLD).  Four loaders = nine waves = three per SIMD
+// leave 168 VGPRs per wave: the compute waves spill (measured 96 us against 63, profiles/ff_tail_r05.txt)
 constexpr int RC_UROWS = 160;                  // weight rows per unit (one 32-row MFMA tile per compute wave)
 constexpr int RC_UNIT = RC_UROWS * 128;        // 20 KB: 160 rows x 64 k fp16
 constexpr int RC_UPIECES = RC_UNIT / 1024;     // LDS-DMA instructions per unit (20, all issued by the loader wave)
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
   constexpr int RING = NS * RC_UNIT;
   constexpr int OFF_XA = RING, OFF_XG = OFF_XA + XBYTES, OFF_AUX = OFF_XG + 2 * XBYTES, OFF_TAB = OFF_AUX + 2 * AUXB;
   constexpr int LDS_TOTAL = OFF_TAB + RC_ROWS * 8;
-  static_assert(NLD == 1 || NLD == 2 || NLD == 4, "loader waves");
+  static_assert(NLD == 1 || NLD == 2, "loader waves");
   constexpr int LPIECES = RC_UPIECES / NLD;           // LDS-DMA instructions per unit and loader wave
   constexpr int LD_WAIT = LPIECES * (NS - 2);         // a loader: its pieces of the NS - 2 youngest units may still be in flight
   static_assert(AUXB == 5 * 1024 && XBYTES == 4 * RC_NTC * 16, "piece counts");
@@ -417,29 +418,40 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
 //                token stream to memory, fp16(gamma1 * t) into the q|k|v operand strip, LayerNorm partials per 32-column block
 //   q, k, v    = igemm_kernel + the LayerNorm-fold correction + the per-head scatter (q, k rows through the LDS slabs, v^T from the
 //                accumulator registers: four consecutive tokens per lane)
-constexpr int SH_NU = 2 * FT_BLK + 3 * FT_BLK;                           // 50 units
-struct ShUnitTab { int soff[SH_NU]; int sel[SH_NU]; };
+//
+// KIND 1, the MIDDLE of a BasicTransformerBlock (same kernel, `if constexpr`):   t += attn1_out Wo^T + b;  q2 = norm2(t) Wq^T
+//     attention.py:212 (x = attn1(norm1(x)) + x: CrossAttention.to_out, :191-192), :213 + :170 (attn2.to_q over norm2(x))
+// -- the out-projection of the self-attention (operand strip by LDS-DMA, residual = the token stream, updated in place) and the query
+// projection of the cross-attention (10 + 10 units) instead of two GEMM launches.
+constexpr int SH_NU = 2 * FT_BLK + 3 * FT_BLK;                           // head: 50 units; middle: the first 20
+struct ShUnitTab { int soff[2][SH_NU]; int sel[2][SH_NU]; };
 constexpr ShUnitTab sh_make_tab() {
   ShUnitTab t{};
   int u = 0;
   for (int kt = 0; kt < FT_KT; ++kt)
     for (int half = 0; half < 2; ++half)
-      for (int lo = 0; lo < 2; ++lo) { t.soff[u] = (32 * half) * (3 * FT_C * 2) + (64 * kt + (lo ? 2 * FT_C : 0)) * 2; t.sel[u] = 0; ++u; }
+      for (int lo = 0; lo < 2; ++lo) { t.soff[0][u] = (32 * half) * (3 * FT_C * 2) + (64 * kt + (lo ? 2 * FT_C : 0)) * 2; t.sel[0][u] = 0; ++u; }
   for (int b = 0; b < 3; ++b)
     for (int kt = 0; kt < FT_KT; ++kt)
-      for (int half = 0; half < 2; ++half) { t.soff[u] = (FT_C * b + 32 * half) * (FT_C * 2) + kt * 128; t.sel[u] = 1; ++u; }
+      for (int half = 0; half < 2; ++half) { t.soff[0][u] = (FT_C * b + 32 * half) * (FT_C * 2) + kt * 128; t.sel[0][u] = 1; ++u; }
+  u = 0;
+  for (int b = 0; b < 2; ++b)                           // middle: Wo [C][C], then Wq [C][C]
+    for (int kt = 0; kt < FT_KT; ++kt)
+      for (int half = 0; half < 2; ++half) { t.soff[1][u] = (32 * half) * (FT_C * 2) + kt * 128; t.sel[1][u] = b; ++u; }
+  for (; u < SH_NU; ++u) { t.soff[1][u] = t.soff[1][2 * FT_BLK - 1]; t.sel[1][u] = 1; }
   return t;
 }
 __device__ const ShUnitTab kShTab = sh_make_tab();
 
-template <int C, int NLD, int NS = RC_NS>
+template <int C, int NLD, int KIND, int NS = RC_NS>
 __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHeadParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C");
   static_assert(NLD == 1 || NLD == 2, "loader waves");
   constexpr int KT = C / 64;
   constexpr int XBYTES = RC_ROWS * C * 2;             // one operand strip (20 KB)
-  constexpr int NU = SH_NU;
+  constexpr int NU = KIND == 0 ? SH_NU : 2 * FT_BLK;    // units of the launch
+  constexpr int NU1 = KIND == 0 ? 2 * FT_BLK : FT_BLK;  // ... of its first GEMM (behind it: barrier X1, the token-stream epilogue)
   constexpr int RING = NS * RC_UNIT;
   constexpr int OFF_XH = RING, OFF_XL = OFF_XH + XBYTES, OFF_XN = OFF_XL + XBYTES;
   constexpr int OFF_GTAB = OFF_XN + XBYTES;           // {mean, rstd} of the sample's 32 GroupNorm groups
@@ -468,13 +480,13 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   if (wave_u >= RC_NWC) {
     // =============================== the loader waves (see ff_tail_kernel) =========================================================
     const int lw = wave_u - RC_NWC;
-    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)rp.w_in, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)rp.w_in, 0, OOB, 0x00020000);      // (middle: Wo [C][C])
     const __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wqkv, 0, OOB, 0x00020000);
     const int l8 = lane >> 3, cpos = lane & 7;
     const int g16_0 = (cpos ^ ((l8 >> 1) & 7)) << 4, g16_1 = (cpos ^ ((4 + (l8 >> 1)) & 7)) << 4;
     auto issue_unit = [&](int soff, int sel, int stage) {
       const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_in : rs_qkv;
-      const int ldw2 = sel == 0 ? 3 * C * 2 : C * 2;
+      const int ldw2 = (KIND == 0 && sel == 0) ? 3 * C * 2 : C * 2;
       const int v0 = l8 * ldw2 + g16_0, v1 = l8 * ldw2 + g16_1;
       const int vv = (lw & 1) ? v1 : v0;
 #pragma unroll
@@ -486,16 +498,16 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
     };
     auto desc = [&](int u, int& soff, int& sel) {
       u = min(u, NU - 1);
-      soff = __builtin_amdgcn_readfirstlane(kShTab.soff[u]);
-      sel = __builtin_amdgcn_readfirstlane(kShTab.sel[u]);
+      soff = __builtin_amdgcn_readfirstlane(kShTab.soff[KIND][u]);
+      sel = __builtin_amdgcn_readfirstlane(kShTab.sel[KIND][u]);
     };
 #pragma unroll
-    for (int s = 0; s < NS - 1; ++s) issue_unit(kShTab.soff[s], kShTab.sel[s], s);
+    for (int s = 0; s < NS - 1; ++s) issue_unit(kShTab.soff[KIND][s], kShTab.sel[KIND][s], s);
     asm volatile("s_barrier" ::: "memory");             // X0: the compute waves' GroupNorm table
     int nxt = NS - 1, d_soff, d_sel;
     desc(NS - 1, d_soff, d_sel);
     for (int g = 0; g < NU; ++g) {
-      if (g == 2 * FT_BLK) asm volatile("s_barrier" ::: "memory");      // X1: proj_in's operand strips are dead (the epilogue slabs go there)
+      if (g == NU1) asm volatile("s_barrier" ::: "memory");             // X1: the first GEMM's operand strips are dead (the epilogue slabs go there)
       wait_vmcnt<LD_WAIT>();                            // unit g has landed
       asm volatile("s_barrier" ::: "memory");           // ... and the compute waves are done with unit g - 1
       issue_unit(d_soff, d_sel, nxt);
@@ -520,17 +532,14 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   // ---- prologue: the strip's fp32 rows (thread -> rows xr + 8 i, channels 8 c8 ... 8 c8 + 7), gamma / beta of those channels, the
   // LayerNorm-fold column terms of this lane's q | k | v columns; then the sample's GroupNorm table ----
   const int xr = tid / 40, c8 = tid - xr * 40;
+  const int rl = lane >> 4, c4 = (lane & 15) * 4;      // the 16-byte epilogues: lane -> row q * 4 + rl of a slab pass, columns nw + c4 ... + 3
+  const int nw = wave * 64;
   f32x4 xv[4][2], gv[2], bv[2];
+  f32x4 resv[8];                                        // middle: the token-stream rows the first epilogue adds (and overwrites)
+  constexpr int NB = KIND == 0 ? 3 : 1;                 // LayerNorm-folding GEMMs behind the token stream
+  float fcs[NB][2], fdn[NB][2];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const float* src = rp.x + (size_t)(m0 + xr + 8 * i) * C + c8 * 8;
-    xv[i][0] = *(const f32x4*)src; xv[i][1] = *(const f32x4*)(src + 4);
-  }
-  gv[0] = *(const f32x4*)(rp.gn_gamma + c8 * 8); gv[1] = *(const f32x4*)(rp.gn_gamma + c8 * 8 + 4);
-  bv[0] = *(const f32x4*)(rp.gn_beta + c8 * 8); bv[1] = *(const f32x4*)(rp.gn_beta + c8 * 8 + 4);
-  float fcs[3][2], fdn[3][2];
-#pragma unroll
-  for (int b = 0; b < 3; ++b)
+  for (int b = 0; b < NB; ++b)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int n = C * b + 64 * wave + 32 * j + l31;
@@ -538,7 +547,29 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
     }
   float2* const gtab = (float2*)(smem + OFF_GTAB);
   float2* const ltab = (float2*)(smem + OFF_LTAB);
-  if (tid < 256) {
+  if constexpr (KIND == 0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float* src = rp.x + (size_t)(m0 + xr + 8 * i) * C + c8 * 8;
+      xv[i][0] = *(const f32x4*)src; xv[i][1] = *(const f32x4*)(src + 4);
+    }
+    gv[0] = *(const f32x4*)(rp.gn_gamma + c8 * 8); gv[1] = *(const f32x4*)(rp.gn_gamma + c8 * 8 + 4);
+    bv[0] = *(const f32x4*)(rp.gn_beta + c8 * 8); bv[1] = *(const f32x4*)(rp.gn_beta + c8 * 8 + 4);
+  } else {
+    // the fp16 operand strip (the attention output rows) by LDS-DMA into strip_off's layout (ff_tail_kernel's prologue), the residual rows
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)rp.a16, 0, OOB, 0x00020000);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = i * RC_NTC + tid;                   // 16 bytes at strip offset 16 q: k-tile q / 256, row (q / 8) % 32, position q % 8
+      const int kt = q >> 8, row = (q >> 3) & 31;
+      const int gch = (q & 7) ^ ((row >> 1) & 7);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (__attribute__((address_space(3))) void*)(smem + OFF_XH + (i * RC_NTC + wave_u * 64) * 16), 16,
+                                               ((m0 + row) * C + kt * 64 + gch * 8) * 2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) resv[q] = *(const f32x4*)(rp.t + (size_t)(m0 + q * 4 + rl) * C + nw + c4);
+  }
+  if (KIND == 0 && tid < 256) {
     // (norm.hip gn_fold: 8 consecutive lanes fold the 8 slots of a group)
     const int g = tid >> 3, sub = tid & 7;
     const long long* src = rp.gn_acc + ((size_t)(bsample * 32 + g) * GN_SLOTS + sub) * GN_STRIDE;
@@ -554,7 +585,7 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
     }
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");        // X0
-  {
+  if constexpr (KIND == 0) {
     // normalise (gn_apply_kernel's expression), split into hi | lo (lo_half), write the two operand strips in strip_off's layout
     constexpr int cpg = C / 32;
     const int c0 = c8 * 8;
@@ -593,8 +624,34 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
 
   // ---- proj_in as split-fp16: per (k-tile, half) the hi unit parks its fragments, the lo unit runs the three products of every k-step
   // in gemm_split16_kernel's order (a_hi w_hi, a_lo w_hi, a_hi w_lo) ----
+  // One block of ten units = the five k-tiles of a K = C GEMM over an operand strip, two column halves each.  first(): run once behind
+  // the first unit's barrier (the LayerNorm table of the rows: every wave's partials are visible there).
+  auto block = [&](f32x16 (&a)[2], int a_base, auto&& first) {
+    rc_static_for<KT>([&](auto ktc) {
+      constexpr int kt = decltype(ktc)::value;
+      f16x8 fa[4], fb[4];
+      unit_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fa[ks] = frag(a_base + kt * (RC_ROWS * 128) + a_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], a[0], 0, 0, 0);
+      if constexpr (kt == 0) first();
+      unit_end();
+      unit_sync();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) a[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], a[1], 0, 0, 0);
+      unit_end();
+    });
+  };
+  auto nothing = []() {};
   f32x16 acc[2];
   zero2(acc);
+  if constexpr (KIND == 1) block(acc, OFF_XH, nothing);                 // the out-projection (plain fp16 operands)
+  if constexpr (KIND == 0)
   rc_static_for<KT>([&](auto ktc) {
     constexpr int kt = decltype(ktc)::value;
     f16x8 ah[4], al[4];
@@ -629,8 +686,6 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   // ---- proj_in epilogue (igemm_epilogue's 16-byte plain path on this wave's 32 x 64 slab): t = acc + bias -> memory (fp32), fp16(gamma1 * t)
   // -> the q | k | v operand strip, {sum, sum of squares} per 32-column block -> the LayerNorm partial table ----
   float* const wl = (float*)(smem + OFF_XH) + wave * (32 * LSTR);
-  const int rl = lane >> 4, c4 = (lane & 15) * 4;
-  const int nw = wave * 64;
   {
     const f32x4 colv = *(const f32x4*)(rp.b_in + nw + c4);
     const f32x4 g4 = *(const f32x4*)(rp.ln_gamma + nw + c4);
@@ -639,7 +694,8 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int row = q * 4 + rl;
-      const f32x4 v = *(const f32x4*)(wl + row * LSTR + c4) + colv;
+      f32x4 v = *(const f32x4*)(wl + row * LSTR + c4) + colv;
+      if constexpr (KIND == 1) v = v + resv[q];
       SDMI_ST_F32X4(rp.t, (size_t)(m0 + row) * C + nw + c4, v);
       const f32x4 vs = v * g4;
       *(f16x4*)(smem + OFF_XN + strip_off(row, nw + c4)) = f16x4{(f16)vs[0], (f16)vs[1], (f16)vs[2], (f16)vs[3]};
@@ -652,29 +708,6 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   }
   SH_STAMP();
 
-  // One block of ten units = the five k-tiles of a K = C GEMM over the operand strip, two column halves each.  first(): run once behind
-  // the first unit's barrier (the LayerNorm table of the rows: every wave's partials are visible there).
-  auto block = [&](f32x16 (&a)[2], auto&& first) {
-    rc_static_for<KT>([&](auto ktc) {
-      constexpr int kt = decltype(ktc)::value;
-      f16x8 fa[4], fb[4];
-      unit_sync();
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fa[ks] = frag(OFF_XN + kt * (RC_ROWS * 128) + a_frag, ks);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], a[0], 0, 0, 0);
-      if constexpr (kt == 0) first();
-      unit_end();
-      unit_sync();
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) fb[ks] = frag(cur * RC_UNIT + b_frag, ks);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) a[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[ks], fb[ks], a[1], 0, 0, 0);
-      unit_end();
-    });
-  };
   auto ln_table = [&]() {
     if (tid < RC_ROWS) {                                // (lnf_finish's fold of the block partials, in block order)
       IGemmParams lq;
@@ -688,7 +721,6 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
       ltab[tid] = float2{mu, rs_};
     }
   };
-  auto nothing = []() {};
   // LayerNorm-fold correction of a finished accumulator pair (igemm_epilogue's expression)
   auto fold = [&](f32x16 (&a)[2], const float (&cs_)[2], const float (&dn_)[2]) {
 #pragma unroll
@@ -715,22 +747,32 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   };
 
   zero2(acc);
-  block(acc, ln_table);                                 // q
+  block(acc, OFF_XN, ln_table);                         // q
   SH_STAMP();
+  if constexpr (KIND == 1) {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (pairs with the loaders' last barrier)
+    fold(acc, fcs[0], fdn[0]);
+    rows_out(acc, rp.q);
+#ifdef SDMI_RC_TIMING
+    SH_STAMP();
+    if (rp.dbg && tid < 64) rp.dbg[(size_t)blockIdx.x * 128 + tid] = tid < n_stamp ? ((const long long*)(smem + OFF_DBG))[tid] : 0;
+#endif
+    return;
+  }
   fold(acc, fcs[0], fdn[0]);
   rows_out(acc, rp.q);
   SH_STAMP();
   zero2(acc);
-  block(acc, nothing);                                  // k
+  block(acc, OFF_XN, nothing);                          // k
   SH_STAMP();
-  fold(acc, fcs[1], fdn[1]);
+  fold(acc, fcs[NB > 1 ? 1 : 0], fdn[NB > 1 ? 1 : 0]);
   rows_out(acc, rp.k);
   SH_STAMP();
   zero2(acc);
-  block(acc, nothing);                                  // v
+  block(acc, OFF_XN, nothing);                          // v
   SH_STAMP();
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // (pairs with the loaders' last barrier)
-  fold(acc, fcs[2], fdn[2]);
+  fold(acc, fcs[NB > 2 ? 2 : 0], fdn[NB > 2 ? 2 : 0]);
   // v^T: [B * heads][dh][ntok_pad] straight from the accumulator registers (lane = column, registers 4 r4 ... 4 r4 + 3 = 4 consecutive tokens)
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -793,10 +835,9 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   const int abl = g_rc_abl % 10, nld = g_rc_abl >= 10 ? g_rc_abl / 10 : nld_env;      // 10 a + x: ablation x with a loader waves
 #define RC_LAUNCH(NLD, ABL) hipLaunchKernelGGL((ff_tail_kernel<320, NLD, ABL>), grid, dim3(RC_NTC + 64 * NLD), 0, stream, q)
 #define RC_ABL(NLD) switch (abl) { case 1: RC_LAUNCH(NLD, 1); break; case 2: RC_LAUNCH(NLD, 2); break; case 3: RC_LAUNCH(NLD, 3); break; default: RC_LAUNCH(NLD, 0); break; }
-  if (nld == 1) { RC_ABL(1) } else if (nld == 4) { RC_ABL(4) } else { RC_ABL(2) }
+  if (nld == 1) { RC_ABL(1) } else { RC_ABL(2) }
 #else
   if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
-  else if (nld_env == 4) hipLaunchKernelGGL((ff_tail_kernel<320, 4>), grid, dim3(RC_NTC + 256), 0, stream, q);
   else hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
 #endif
   SDMI_HIP_OK(hipGetLastError());
@@ -830,8 +871,28 @@ int launch_st_head(const StHeadParams& p, hipStream_t stream) {
 #ifdef SDMI_RC_TIMING
   q.dbg = g_sh_dbg;
 #endif
-  if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
-  else hipLaunchKernelGGL((st_head_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 0>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else hipLaunchKernelGGL((st_head_kernel<320, 2, 0>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
+
+// the middle of a BasicTransformerBlock: t += a16 Wo^T + b (in place), q = norm2(t) Wq^T (StHeadParams: a16, w_in = Wo [C][C], b_in, t,
+// ln_gamma = norm2 weight, wqkv = Wq [C][C], lnf_cs / lnf_d [C], q)
+int launch_st_mid(const StHeadParams& p, hipStream_t stream) {
+  SDMI_CHECK(st_head_supported(p.C, p.M, p.ntok, p.ntok_pad > 0 ? p.ntok_pad : p.ntok, p.heads, p.dh), "st_mid: C = 320, rows (per sample) multiples of 32, heads * dh = C, dh % 4 = 0");
+  SDMI_CHECK(p.a16 && p.w_in && p.b_in && p.t && p.ln_gamma && p.wqkv && p.lnf_cs && p.lnf_d && p.q, "st_mid: null operand");
+  SDMI_CHECK(p.B * p.ntok == p.M, "st_mid: M = B * ntok");
+  const double M = p.M, C = p.C;
+  ProfScope ps("st_mid_32x320w5", 2.0 * M * (2.0 * C * C), M * C * (2.0 + 4.0 + 4.0 + 2.0) + 2.0 * C * C * 2.0, stream);
+  StHeadParams q = p;
+  const dim3 grid(p.M / RC_ROWS);
+  const int nld = env_int("SDMI_FF_TAIL_LD", RC_NLD_DEFAULT);
+#ifdef SDMI_RC_TIMING
+  q.dbg = g_sh_dbg;
+#endif
+  if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else hipLaunchKernelGGL((st_head_kernel<320, 2, 1>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -461,6 +461,7 @@ struct Fwd : FwdBase {
   bool ln_fold_on = false;      // this call folds LayerNorms into their consuming GEMMs (UNet::ln_fold_; read per call: A/B knobs)
   bool ff_tail_on = false;      // ... and runs SpatialTransformer tails as row-strip chain launches (UNet::ff_tail_; SDMI_FF_TAIL, read per call)
   bool st_head_on = false;      // ... and SpatialTransformer heads (UNet::st_head_; SDMI_ST_HEAD, read per call)
+  bool st_mid_on = false;       // ... and the out-projection of attn1 with attn2's to_q (SDMI_ST_MID)
   // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
   bool fuse_ctx_q = false;
@@ -655,7 +656,16 @@ struct Fwd : FwdBase {
         gemm(p);
       }
       attention(q, k, vt, ao, L, N, N, Np, scale);
-      {
+      // attn1's out-projection (+ x) and attn2's to_q over norm2 as one row-strip chain launch (rowchain.hip, st_head_kernel KIND 1)
+      const bool ctx_fused_here = fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx) && !(fold_ln && C > 640);
+      const bool chain_mid = st_mid_on && fold_ln && !ctx_fused_here && T.lnf[2] != nullptr && st_head_supported(C, M, N, Np, L.heads, L.dh);
+      if (chain_mid) {
+        StHeadParams h;
+        h.a16 = ao; h.w_in = T.wo1; h.b_in = T.bo1; h.t = t; h.ln_gamma = T.ln[2]; h.ln_eps = 1e-5f;
+        h.wqkv = T.wq2; h.lnf_cs = T.lnf[2]; h.lnf_d = T.lnf[3]; h.q = q;
+        h.M = M; h.B = B; h.ntok = N; h.ntok_pad = Np; h.heads = L.heads; h.dh = L.dh; h.C = C;
+        if (!dry && !rc) ok(launch_st_mid(h, s));
+      } else {
         IGemmParams p = dense(ao, M, C, T.wo1, C, N);
         p.bias = T.bo1; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
         with_ln(p, T.ln[2], T.ln[3]);                                // norm2
@@ -663,7 +673,9 @@ struct Fwd : FwdBase {
       }
       // x = attn2(norm2(x), context) + x                           attention.py:213
       if (ctx16) context_kv(L, d);
-      if (fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx) && !(fold_ln && C > 640)) {
+      if (chain_mid) {
+        attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);       // (q = to_q(norm2(t)) came out of the chain launch)
+      } else if (fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx) && !(fold_ln && C > 640)) {
         // to_q inside the attention kernel (attn_ctx.hip): one launch for q = norm2(x) Wq^T and softmax(q K^T) V
         AttnCtxParams a;
         a.x = ln; a.wq = T.wq2; a.k = T.ck; a.vt = T.cvt; a.out = ao;
@@ -877,6 +889,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     f.ff_tail_on = e_ff ? atoi(e_ff) != 0 : ff_tail_;
     const char* e_sh = getenv("SDMI_ST_HEAD");
     f.st_head_on = e_sh ? atoi(e_sh) != 0 : st_head_;
+    const char* e_sm = getenv("SDMI_ST_MID");
+    f.st_mid_on = e_sm ? atoi(e_sm) != 0 : st_head_;
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);

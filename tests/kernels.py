@@ -126,6 +126,12 @@ def st_head(x, gn_gamma, gn_beta, gn_eps, w_in3, b_in, t, ln_gamma, ln_eps, wqkv
                                           B, ntok, vt.shape[2], heads, dh, C_, _s()))
 
 
+def st_mid(a16, wo16, bo, t, ln_gamma, ln_eps, wq16, cs, dn, q, B, ntok, heads, dh):
+    """t += a16 Wo^T + bo (in place), q = norm2(t) Wq^T per head, as one launch (sdmi_k_st_mid)"""
+    _lib.check(_lib.load().sdmi_k_st_mid(a16.data_ptr(), wo16.data_ptr(), bo.data_ptr(), t.data_ptr(), ln_gamma.data_ptr(), float(ln_eps),
+                                         wq16.data_ptr(), cs.data_ptr(), dn.data_ptr(), q.data_ptr(), B, ntok, heads, dh, a16.shape[1], _s()))
+
+
 _CNT = {}
 
 

@@ -213,3 +213,36 @@ def test_st_head_repeats_bit_identically_next_to_other_work():
             ref = (t, q, k, vt)
         else:
             assert all(torch.equal(a, b) for a, b in zip((t, q, k, vt), ref)), i
+
+
+@pytest.mark.parametrize('B,ntok', [(2, 4096), (1, 64), (3, 128), (2, 9216)])
+def test_st_mid_is_bit_identical_to_the_two_launches(B, ntok):
+    """out-projection of attn1 (+ residual, in place) and attn2's to_q over norm2 (attention.py:212-213) as one launch"""
+    g = _g(977 + ntok)
+    C_, heads = 320, 8
+    dh, M = C_ // heads, B * ntok
+    d = lambda t: t.to(DEV)
+    ao = (torch.randn(M, C_, generator=g) * 0.7).half()
+    wo = (torch.randn(C_, C_, generator=g) / math.sqrt(C_)).half()
+    bo = torch.randn(C_, generator=g) * 0.1
+    t_prev = torch.randn(M, C_, generator=g) * 1.5 + 0.3
+    ln_g = 1 + 0.2 * torch.randn(C_, generator=g); ln_b = 0.1 * torch.randn(C_, generator=g)
+    wq = (torch.randn(C_, C_, generator=g) / math.sqrt(C_)).half()
+    cs, dn = K.ln_fold_prep(d(wq), C_, d(ln_g), d(ln_b))
+    # the two launches
+    t0 = d(t_prev).clone(); ln16 = torch.empty(M, C_, dtype=torch.float16, device=DEV)
+    part = torch.full((C_ // 32, M, 2), float('nan'), device=DEV)
+    K.igemm(d(ao), d(wo), C_, B, ntok, 1, ntok, 1, bias=d(bo), residual=t0, out_f32=t0, out_f16=ln16, f16_scale=d(ln_g), lnp_out=part)
+    q0 = torch.full((B * heads, ntok, dh), float('nan'), dtype=torch.float16, device=DEV)
+    K.igemm(ln16, d(wq), C_, B, ntok, 1, ntok, 1, mode=2, lnf=(part, 1e-5, cs, dn),
+            heads=dict(segs=[(q0, 0)], heads=heads, dh=dh, ntok=ntok, ntok_pad=(ntok + 7) // 8 * 8, segC=C_))
+    # one launch
+    t = d(t_prev).clone(); q = torch.full_like(q0, float('nan'))
+    K.st_mid(d(ao), d(wo), d(bo), t, d(ln_g), 1e-5, d(wq), cs, dn, q, B, ntok, heads, dh)
+    torch.cuda.synchronize()
+    t_ref = t_prev + ao.float() @ wo.float().t() + bo
+    q_ref = (F.layer_norm(t_ref, (C_,), ln_g, ln_b, 1e-5) @ wq.float().t()).reshape(B, ntok, heads, dh).permute(0, 2, 1, 3).reshape(B * heads, ntok, dh)
+    assert K.report(f'st_mid t B{B} n{ntok}', t, t_ref, 2e-3) < 2e-3
+    assert K.report(f'st_mid q B{B} n{ntok}', q.float(), q_ref, 2e-2) < 2e-2
+    print(f'[st_mid vs launches] t / q equal: {torch.equal(t, t0)} {torch.equal(q, q0)}', flush=True)
+    assert torch.equal(t, t0) and torch.equal(q, q0)

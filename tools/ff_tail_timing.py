@@ -31,7 +31,7 @@ def one():
 
 
 NAMES = ['P0(0)', 'P1(0)', 'P0(1)', 'P1(1)', 'FF(0)', 'P0(2)', 'P1(2)', 'FF(1)', 'P0(3)', 'P1(3)', 'FF(2)', 'FF(3)']
-for abl in (20, 21, 22, 23, 10, 11, 40, 41):      # 10 a + x: ablation x with a loader waves
+for abl in (20, 21, 22, 23, 10, 11):      # 10 a + x: ablation x with a loader waves
     dbg_fn(stamps.data_ptr(), abl)
     for _ in range(5):
         one()
