@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 13
+#define SDMI_ABI_VERSION 14
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -254,6 +254,11 @@ int sdmi_k_igemm(const sdmi_igemm_desc* d, void* stream);
  * hidden chunk of C: [4][cs of 2C packed columns | d of the same 2C]; wgg [8C][C], wff2 [C][4C] fp16, bff2 [C], t [M][C] fp32. */
 int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const float* lnp, float ln_eps, const float* csd,
                    const void* wgg_f16, const void* wff2_f16, const float* bff2, const float* t, void* stream);
+/* ... with the out-projection of the cross-attention in front (ABI 14; the same kernel; attention.py:213, 191-192): t += a Wo^T + bo in place
+ * (a [M][C] fp16 = the attn2 output rows, wo [C][C] fp16, t [M][C] fp32 in / out), then the chain above over norm3(t) with ln_gamma = the norm3
+ * weight (its bias lives in csd).  The same bits as sdmi_k_igemm (bias, residual = t, out_f32 = t, f16_scale, lnp_out) -> sdmi_k_ff_tail. */
+int sdmi_k_st_tail(const sdmi_igemm_desc* proj_out, const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma,
+                   float ln_eps, const float* csd, const void* wgg_f16, const void* wff2_f16, const float* bff2, void* stream);
 /* GroupNorm-apply -> proj_in -> q | k | v of a SpatialTransformer as ONE launch (ABI 13; csrc/rowchain.hip; ldm/modules/attention.py:254-256,
  * 212, 170-176): t = proj_in(GroupNorm(x)) + b_in (fp32 [M][C], M = B * ntok), q | k | v = norm1(t) Wqkv^T scattered per head
  * (q, k: [B * heads][ntok][dh] fp16, vt: [B * heads][dh][ntok_pad] fp16) for C = 320 channels, a workgroup per 32 token rows.

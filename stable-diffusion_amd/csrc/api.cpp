@@ -278,6 +278,16 @@ int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const fl
   q.bff2 = bff2; q.t = t; q.wpo = (const f16*)proj_out->w;
   return launch_ff_tail(q, (hipStream_t)stream);
 }
+int sdmi_k_st_tail(const sdmi_igemm_desc* proj_out, const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma,
+                   float ln_eps, const float* csd, const void* wgg_f16, const void* wff2_f16, const float* bff2, void* stream) {
+  SDMI_CHECK(proj_out && a_f16, "null argument");
+  FfTailParams q;
+  if (igemm_params_of(proj_out, q.epi)) return -1;
+  SDMI_CHECK(proj_out->split16 && proj_out->ksize == 1, "st_tail: the proj_out descriptor is a split-fp16 1x1 (w = sdmi_k_pack_split3)");
+  q.a16 = (const f16*)a_f16; q.wo = (const f16*)wo_f16; q.bo = bo; q.ln_gamma = ln_gamma; q.ln_eps = ln_eps; q.csd = csd;
+  q.wgg = (const f16*)wgg_f16; q.wff2 = (const f16*)wff2_f16; q.bff2 = bff2; q.t = t; q.wpo = (const f16*)proj_out->w;
+  return launch_ff_tail(q, (hipStream_t)stream);
+}
 int sdmi_k_st_head(const float* x, float* gn_ws, int64_t gn_ws_floats, const float* gn_gamma, const float* gn_beta, float gn_eps,
                    const void* w_in3, const float* b_in, float* t, const float* ln_gamma, float ln_eps, const void* wqkv_f16,
                    const float* lnf_cs, const float* lnf_d, void* q, void* k, void* vt, int B, int ntok, int ntok_pad, int heads, int dh,

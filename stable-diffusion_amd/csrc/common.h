@@ -293,6 +293,12 @@ struct FfTailParams {
   const float* bff2 = nullptr;    // [C]
   const float* t = nullptr;       // [M][C] fp32 token stream (residual of FF-out)
   const f16* wpo = nullptr;       // [C][3C] split-fp16 proj_out weights [hi | hi | lo]
+  // the out-projection of attn2 in front (a16 != nullptr; `ln` / `lnp` are then unused, t is updated in place): t += a16 Wo^T + bo,
+  // the GEGLU operand fp16(ln_gamma * t) and its row statistics stay on the CU                 attention.py:213, 191-192
+  const f16* a16 = nullptr;       // [M][C] fp16: the cross-attention output rows
+  const f16* wo = nullptr;        // [C][C] attn2.to_out weights
+  const float* bo = nullptr;      // [C]
+  const float* ln_gamma = nullptr;  // [C] norm3 weight
 #ifdef SDMI_RC_TIMING
   long long* dbg = nullptr;       // timing build only: [workgroups][128] s_memtime stamps
 #endif

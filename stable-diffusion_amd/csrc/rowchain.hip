@@ -57,15 +57,19 @@ constexpr int RC_NLD_DEFAULT = 2;
 constexpr int FT_C = 320, FT_KT = FT_C / 64, FT_HID = 4 * FT_C, FT_NCHUNK = 4;
 constexpr int FT_BLK = 2 * FT_KT;                                          // units per block (10)
 constexpr int FT_NU = (3 * FT_NCHUNK) * FT_BLK + 2 * FT_BLK;              // 12 GEGLU / FF-out blocks + proj_out {hi, lo} pairs (140)
+constexpr int FT_NUH = FT_NU + FT_BLK;                                    // ... behind the out-projection of attn2 (HEAD launches: 150)
 struct FtUnitTab {
-  int soff[FT_NU];      // source byte offset of the unit inside its weight matrix: row0 * row pitch + k offset
-  int sel[FT_NU];       // 0 GEGLU weights (row pitch C), 1 FF-out (4C), 2 proj_out split-fp16 (3C)
-  int aux[FT_NU];       // at the barrier of unit g: >= 0: issue the {cs, d} column terms of that hidden chunk; -2: prefetch the x_in rows
+  int soff[FT_NUH];     // source byte offset of the unit inside its weight matrix: row0 * row pitch + k offset
+  int sel[FT_NUH];      // 0 GEGLU weights (row pitch C), 1 FF-out (4C), 2 proj_out split-fp16 (3C), 3 attn2's to_out (C)
+  int aux[FT_NUH];      // at the barrier of unit g: >= 0: issue the {cs, d} column terms of that hidden chunk; -2: prefetch the x_in rows
 };
+// entries 0 ... FT_BLK - 1: the out-projection of attn2 (HEAD launches start there, the others at FT_BLK)
 constexpr FtUnitTab ft_make_tab() {
   FtUnitTab t{};
   int u = 0;
-  for (int i = 0; i < FT_NU; ++i) t.aux[i] = -1;
+  for (int i = 0; i < FT_NUH; ++i) t.aux[i] = -1;
+  for (int kt = 0; kt < FT_KT; ++kt)
+    for (int half = 0; half < 2; ++half) { t.soff[u] = (32 * half) * (FT_C * 2) + kt * 128; t.sel[u] = 3; ++u; }
   for (int h = 0; h <= FT_NCHUNK; ++h) {
     if (h < FT_NCHUNK) {
       for (int pass = 0; pass < 2; ++pass) {
@@ -104,18 +108,25 @@ __device__ __forceinline__ void rc_static_for(F&& f) { rc_static_for_impl(std::m
 
 // ABL (timing build only, -DSDMI_RC_TIMING; WRONG results): 1 = the compute waves only keep the barriers (the stream alone),
 // 2 = the loader only keeps the barriers (the compute side alone), 3 = no GEGLU arithmetic
-template <int C, int NLD, int ABL = 0, int NS = RC_NS>
+// HEAD: the out-projection of attn2 in front (FfTailParams::a16 ...): t += a16 Wo^T + bo in place, the LayerNorm-folded GEGLU operand strip
+// fp16(gamma3 * t) and the row statistics stay in LDS -- st_head_kernel's KIND 1 first stage (the same bits as the igemm launch it replaces:
+// bias, residual = t, out_f32 = t, f16_scale, lnp_out)                 attention.py:213 (x = attn2(norm2(x), context) + x: to_out, :191-192)
+template <int C, int NLD, int ABL = 0, int NS = RC_NS, bool HEAD = false>
 __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTailParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C; the unit table is generated for it");
   constexpr int KT = C / 64;                          // k-tiles of a K = C GEMM piece (5)
   constexpr int XBYTES = RC_ROWS * C * 2;             // one operand strip (20 KB)
   constexpr int HID = 4 * C, NCHUNK = HID / C;        // hidden dimension walked in chunks of C (4)
-  constexpr int NU = FT_NU;
+  constexpr int NU = HEAD ? FT_NUH : FT_NU;
+  constexpr int TB = HEAD ? 0 : FT_BLK;               // first entry of kFtTab of this launch
   constexpr int AUXB = 2 * (2 * C) * 4;               // {cs, d} of one chunk's 2C packed GEGLU columns (5 KB)
   constexpr int RING = NS * RC_UNIT;
   constexpr int OFF_XA = RING, OFF_XG = OFF_XA + XBYTES, OFF_AUX = OFF_XG + 2 * XBYTES, OFF_TAB = OFF_AUX + 2 * AUXB;
-  constexpr int LDS_TOTAL = OFF_TAB + RC_ROWS * 8;
+  constexpr int OFF_LNP = OFF_TAB + RC_ROWS * 8;      // (HEAD) [row][C / 32] {sum, sum of squares} of the token stream's 32-column blocks
+  constexpr int LDS_TOTAL = OFF_LNP + (HEAD ? RC_ROWS * (C / 32) * 8 : 0);
+  constexpr int LSTR = 64;                            // (HEAD) row pitch (floats) of the out-projection's epilogue slabs: five 32 x 64 fp32 = the two GEGLU strips
+  static_assert(RC_NWC * 32 * LSTR * 4 <= 2 * XBYTES, "the epilogue slabs live in the (still unused) hidden-chunk strips");
   static_assert(NLD == 1 || NLD == 2, "loader waves");
   constexpr int LPIECES = RC_UPIECES / NLD;           // LDS-DMA instructions per unit and loader wave
   constexpr int LD_WAIT = LPIECES * (NS - 2);         // a loader: its pieces of the NS - 2 youngest units may still be in flight
@@ -149,14 +160,15 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
     const __amdgpu_buffer_rsrc_t rs_ff = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wff2, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_po = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wpo, 0, OOB, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc((void*)ep.residual, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)(HEAD ? rp.wo : rp.wgg), 0, OOB, 0x00020000);
     // piece p of a unit = LDS rows 8 p ... 8 p + 7 (lane -> row 8 p + lane / 8, 16-byte position lane % 8): weight row
     // 64 (p / 4) + 8 (p % 4) + lane / 8 of the unit (tile slot p / 4 = the compute wave that owns it), source chunk (lane % 8) ^ swizzle
     // of the LDS row = (lane % 8) ^ ((4 (p % 2) + lane / 16) % 8): two voffset variants, everything else is scalar
     const int l8 = lane >> 3, cpos = lane & 7;
     const int g16_0 = (cpos ^ ((l8 >> 1) & 7)) << 4, g16_1 = (cpos ^ ((4 + (l8 >> 1)) & 7)) << 4;
     auto issue_unit = [&](int soff, int sel, int stage) {
-      const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_gg : (sel == 1 ? rs_ff : rs_po);
-      const int ldw2 = sel == 0 ? C * 2 : (sel == 1 ? HID * 2 : 3 * C * 2);
+      const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_gg : (sel == 1 ? rs_ff : (sel == 2 ? rs_po : rs_wo));
+      const int ldw2 = (sel == 0 || sel == 3) ? C * 2 : (sel == 1 ? HID * 2 : 3 * C * 2);
       const int v0 = l8 * ldw2 + g16_0, v1 = l8 * ldw2 + g16_1;
       const int vv = (lw & 1) ? v1 : v0;                // (NLD = 2, 4: the parity of a loader's pieces is its own)
 #pragma unroll
@@ -184,21 +196,22 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
     };
     auto desc = [&](int u, int& soff, int& sel) {        // (past the end: the last unit again -- in bounds, never consumed)
       u = min(u, NU - 1);
-      soff = __builtin_amdgcn_readfirstlane(kFtTab.soff[u]);
-      sel = __builtin_amdgcn_readfirstlane(kFtTab.sel[u]);
+      soff = __builtin_amdgcn_readfirstlane(kFtTab.soff[TB + u]);
+      sel = __builtin_amdgcn_readfirstlane(kFtTab.sel[TB + u]);
     };
     if constexpr (ABL != 2) {
       if (lw == 0) issue_aux(0);
 #pragma unroll
       for (int s = 0; s < NS - 1; ++s) {
         if (s == 2) wait_vmcnt<LD_WAIT>();              // (one loader: 5 + 40 in flight -- make room in the 6-bit counter)
-        issue_unit(kFtTab.soff[s], kFtTab.sel[s], s);
+        issue_unit(kFtTab.soff[TB + s], kFtTab.sel[TB + s], s);
       }
     }
     int nxt = NS - 1, d_soff, d_sel, d_aux;
     desc(NS - 1, d_soff, d_sel);
-    d_aux = __builtin_amdgcn_readfirstlane(kFtTab.aux[0]);
+    d_aux = __builtin_amdgcn_readfirstlane(kFtTab.aux[TB]);
     for (int g = 0; g < NU; ++g) {
+      if (HEAD && g == FT_BLK) asm volatile("s_barrier" ::: "memory");  // X1: the out-projection's operand strip is dead (its epilogue slabs go there)
       if constexpr (ABL != 2) wait_vmcnt<LD_WAIT>();    // unit g has landed
       asm volatile("s_barrier" ::: "memory");           // ... and the compute waves are done with unit g - 1
       if constexpr (ABL != 2) {
@@ -209,7 +222,7 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
         issue_unit(d_soff, d_sel, nxt);
       }
       desc(g + NS, d_soff, d_sel);
-      d_aux = __builtin_amdgcn_readfirstlane(kFtTab.aux[min(g + 1, NU - 1)]);
+      d_aux = __builtin_amdgcn_readfirstlane(kFtTab.aux[TB + min(g + 1, NU - 1)]);
       nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
     }
     wait_vmcnt<0>();                                    // the surplus refills: the ring becomes the epilogue's scratch
@@ -222,27 +235,43 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
   RC_STAMP();
   // LayerNorm row partials (register loads) and this wave's share of the LayerNorm-folded operand strip (LDS-DMA): the only vector
   // memory the compute waves touch before the FF-out residual
+  // (HEAD: the operand strip of the out-projection -- the cross-attention output rows -- into hidden-chunk strip 0, and the token-stream rows,
+  // bias and norm3 weight of the 16-byte epilogue: lane -> row 4 q + rl of a slab pass, columns nw + c4 ... + 3)
   IGemmParams lq;                                       // (lnf_request / lnf_finish read these four fields)
   lq.lnf_part = rp.lnp; lq.lnf_npart = C / 32; lq.M = ep.M; lq.lnf_eps = rp.ln_eps;
   float2 lnf_pv[LNF_MAXP];
-  if (tid < RC_ROWS) lnf_request(lq, m0 + tid, lnf_pv);
+  // (an opaque copy of the lane id: the same row / column expressions appear in the final epilogue 140 units later, and values shared
+  // with it would be carried -- spilled -- across the whole main loop)
+  int lane_h = lane;
+  asm volatile("" : "+v"(lane_h));
+  const int rl = lane_h >> 4, c4 = (lane_h & 15) * 4, nw = (tid - lane_h);
+  f32x4 resv[8], colv, g4;
+  if constexpr (!HEAD) { if (tid < RC_ROWS) lnf_request(lq, m0 + tid, lnf_pv); }
   {
-    const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc((void*)rp.ln, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ln = __builtin_amdgcn_make_buffer_rsrc((void*)(HEAD ? rp.a16 : rp.ln), 0, OOB, 0x00020000);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int q = i * RC_NTC + tid;                   // 16 bytes at strip offset 16 q: k-tile q / 256, row (q / 8) % 32, position q % 8
       const int kt = q >> 8, row = (q >> 3) & 31;
       const int gch = (q & 7) ^ ((row >> 1) & 7);
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ln, (__attribute__((address_space(3))) void*)(smem + OFF_XA + (i * RC_NTC + wave_u * 64) * 16), 16,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_ln, (__attribute__((address_space(3))) void*)(smem + (HEAD ? OFF_XG : OFF_XA) + (i * RC_NTC + wave_u * 64) * 16), 16,
                                                ((m0 + row) * C + kt * 64 + gch * 8) * 2, 0, 0, 0);
     }
   }
+  if constexpr (HEAD) {
+#pragma unroll
+    for (int q = 0; q < 8; ++q) resv[q] = *(const f32x4*)(rp.t + (size_t)(m0 + q * 4 + rl) * C + nw + c4);
+    colv = *(const f32x4*)(rp.bo + nw + c4);
+    g4 = *(const f32x4*)(rp.ln_gamma + nw + c4);
+  }
   wait_vmcnt<0>();                                      // (both kinds: the only full drain of these waves before the residual)
   float2* const tab = (float2*)(smem + OFF_TAB);        // {mean, rstd} of the strip's rows
-  if (tid < RC_ROWS) {
-    float mu, rs_;
-    lnf_finish(lq, lnf_pv, &mu, &rs_);
-    tab[tid] = float2{mu, rs_};
+  if constexpr (!HEAD) {
+    if (tid < RC_ROWS) {
+      float mu, rs_;
+      lnf_finish(lq, lnf_pv, &mu, &rs_);
+      tab[tid] = float2{mu, rs_};
+    }
   }
   RC_STAMP();
 
@@ -314,11 +343,53 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
   };
 
   f32x16 accA[2], accB[2], acc2[2];                     // GEGLU pass 0 / pass 1 of the running chunk, FF-out (all hidden chunks)
+  if constexpr (HEAD) {
+    // ---- t += a16 Wo^T + bo (st_head_kernel KIND 1: the same block, the same 16-byte epilogue) ----
+    zero2(accA);
+    block(OFF_XG, accA[0], accA[1], no_carry);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // X1: every wave is done reading the operand strip
+    if constexpr (ABL != 1) {
+      float* const wl = (float*)(smem + OFF_XG) + wave * (32 * LSTR);
+      float2* const lnp = (float2*)(smem + OFF_LNP);
+      slab_put<2, LSTR>(wl, accA, l31, lg);
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int row = q * 4 + rl;
+        f32x4 v = *(const f32x4*)(wl + row * LSTR + c4) + colv;
+        v = v + resv[q];
+        SDMI_ST_F32X4(const_cast<float*>(rp.t), (size_t)(m0 + row) * C + nw + c4, v);
+        const f32x4 vs = v * g4;
+        *(f16x4*)(smem + OFF_XA + strip_off(row, nw + c4)) = f16x4{(f16)vs[0], (f16)vs[1], (f16)vs[2], (f16)vs[3]};
+        float s1 = (v[0] + v[1]) + (v[2] + v[3]);
+        float s2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        s1 = sum8_dpp(s1); s2 = sum8_dpp(s2);
+        if ((lane & 7) == 0) lnp[row * (C / 32) + ((nw + c4) >> 5)] = float2{s1, s2};
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    RC_STAMP();
+  }
+  // (HEAD) the {mean, rstd} table of the strip's rows from the LDS partials (lnf_finish's fold, block order), behind the first unit's barrier:
+  // every wave's partials are visible there, and the first reader is the arithmetic carried by P1(0)
+  auto ln_table = [&]() {
+    if (tid < RC_ROWS) {
+      const float2* pp = (const float2*)(smem + OFF_LNP) + tid * (C / 32);
+      float2 pv[LNF_MAXP];
+#pragma unroll
+      for (int j = 0; j < LNF_MAXP; ++j) pv[j] = j < C / 32 ? pp[j] : float2{0.f, 0.f};
+      float mu, rs_;
+      lnf_finish(lq, pv, &mu, &rs_);
+      tab[tid] = float2{mu, rs_};
+    }
+  };
   zero2(acc2); zero2(accB);
   for (int h = 0; h < NCHUNK; ++h) {
     // P0(h), carrying the arithmetic of P1(h - 1)
     zero2(accA);
-    block(OFF_XA, accA[0], accA[1], [&](auto uc) { if (h > 0) geglu_rows(uc, accB[0], accB[1], h - 1, 1); });
+    block(OFF_XA, accA[0], accA[1], [&](auto uc) {
+      if constexpr (HEAD && decltype(uc)::value == 0) { if (h == 0) ln_table(); }
+      if (h > 0) geglu_rows(uc, accB[0], accB[1], h - 1, 1);
+    });
     // P1(h), carrying the arithmetic of P0(h)
     zero2(accB);
     block(OFF_XA, accB[0], accB[1], [&](auto uc) { geglu_rows(uc, accA[0], accA[1], h, 0); });
@@ -808,7 +879,9 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   const IGemmParams& e = p.epi;
   const int C = e.N;
   SDMI_CHECK(ff_tail_supported(C, e.M, e.Hout * e.Wout), "ff_tail: C = 320, rows (per sample) multiples of 32");
-  SDMI_CHECK(p.ln && p.lnp && p.csd && p.wgg && p.wff2 && p.bff2 && p.t && p.wpo, "ff_tail: null operand");
+  const bool head = p.a16 != nullptr;
+  SDMI_CHECK((head || (p.ln && p.lnp)) && p.csd && p.wgg && p.wff2 && p.bff2 && p.t && p.wpo, "ff_tail: null operand");
+  SDMI_CHECK(!head || (p.wo && p.bo && p.ln_gamma), "ff_tail: the out-projection in front needs wo, bo and the norm3 weight");
   SDMI_CHECK(e.mode == EPI_PLAIN && e.K == C && e.M == e.B * e.Hout * e.Wout && e.out_f32 && e.ldo % 4 == 0, "ff_tail: proj_out descriptor");
   SDMI_CHECK(e.residual && e.ldr >= C, "ff_tail: proj_out adds the SpatialTransformer's input (residual)");
   SDMI_CHECK(!e.lnf_part && !e.lnp_out && !e.f16_scale && !e.ln_out && !e.out_lo && !e.rowvec, "ff_tail: plain proj_out epilogue only");
@@ -825,19 +898,23 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   for (int t = 0; t < e.gn_n; ++t) q.epi.gn_magic[t] = div_magic(e.gn_cpg[t]);
   const double M = e.M;
   // algorithmic work of the three reference ops (one fp16 read of each operand / weight, the fp32 stream in and out)
-  ProfScope ps("ff_tail_32x320w5", 2.0 * M * (8.0 * C * C + 4.0 * C * C + (double)C * C),
-               M * C * (2.0 + 4.0 + 4.0 + 4.0 + (e.out_f16 ? 2.0 : 0.0)) + 13.0 * C * C * 2.0, stream,
-               2.0 * M * (8.0 * C * C + 4.0 * C * C + 3.0 * C * C));
+  ProfScope ps(head ? "st_tail_32x320w5" : "ff_tail_32x320w5", 2.0 * M * (8.0 * C * C + 4.0 * C * C + (double)C * C + (head ? (double)C * C : 0.0)),
+               M * C * (2.0 + 4.0 + 4.0 + 4.0 + (head ? 4.0 : 0.0) + (e.out_f16 ? 2.0 : 0.0)) + (head ? 14.0 : 13.0) * C * C * 2.0, stream,
+               2.0 * M * (8.0 * C * C + 4.0 * C * C + 3.0 * C * C + (head ? (double)C * C : 0.0)));
   const dim3 grid(e.M / RC_ROWS);
   const int nld_env = env_int("SDMI_FF_TAIL_LD", RC_NLD_DEFAULT);      // loader waves (read per launch: A/B)
 #ifdef SDMI_RC_TIMING
   q.dbg = g_rc_dbg;
   const int abl = g_rc_abl % 10, nld = g_rc_abl >= 10 ? g_rc_abl / 10 : nld_env;      // 10 a + x: ablation x with a loader waves
+  SDMI_CHECK(!head, "ff_tail timing build: the out-projection in front is not instantiated");
 #define RC_LAUNCH(NLD, ABL) hipLaunchKernelGGL((ff_tail_kernel<320, NLD, ABL>), grid, dim3(RC_NTC + 64 * NLD), 0, stream, q)
 #define RC_ABL(NLD) switch (abl) { case 1: RC_LAUNCH(NLD, 1); break; case 2: RC_LAUNCH(NLD, 2); break; case 3: RC_LAUNCH(NLD, 3); break; default: RC_LAUNCH(NLD, 0); break; }
   if (nld == 1) { RC_ABL(1) } else { RC_ABL(2) }
 #else
-  if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  if (head) {
+    if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1, 0, RC_NS, true>), grid, dim3(RC_NTC + 64), 0, stream, q);
+    else hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  } else if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
   else hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
 #endif
   SDMI_HIP_OK(hipGetLastError());

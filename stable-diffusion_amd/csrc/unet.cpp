@@ -462,6 +462,7 @@ struct Fwd : FwdBase {
   bool ff_tail_on = false;      // ... and runs SpatialTransformer tails as row-strip chain launches (UNet::ff_tail_; SDMI_FF_TAIL, read per call)
   bool st_head_on = false;      // ... and SpatialTransformer heads (UNet::st_head_; SDMI_ST_HEAD, read per call)
   bool st_mid_on = false;       // ... and the out-projection of attn1 with attn2's to_q (SDMI_ST_MID)
+  bool st_tail_on = false;      // ... and the out-projection of attn2 in front of the tail's chain launch (SDMI_ST_TAIL)
   // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
   bool fuse_ctx_q = false;
@@ -640,6 +641,7 @@ struct Fwd : FwdBase {
     // LayerNorm fold on, split-fp16 proj_out, C = 320 (UNet::ff_tail_)
     const bool chain_ff = ff_tail_on && fold_ln && precise_1x1 && depth == 1 && L.tb[0].lnf_csd != nullptr && ff_tail_supported(C, M, N) &&
                           dense1x1(nullptr, nullptr, M, C, L.w16[1], C, N).split16;
+    const bool chain_tail = chain_ff && st_tail_on;      // ... with attn2's out-projection in front (ff_tail_kernel HEAD)
     for (int d = 0; d < depth; ++d) {
       TBlock& T = L.tb[d];
       // x = attn1(norm1(x)) + x                                   attention.py:212
@@ -690,7 +692,7 @@ struct Fwd : FwdBase {
         gemm(p);
         attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);
       }
-      {
+      if (!chain_tail) {                     // (else: inside the chain launch below)
         IGemmParams p = dense(ao, M, C, T.wo2, C, N);
         p.bias = T.bo2; p.residual = t; p.ldr = C; p.out_f32 = t; p.ldo = C;
         with_ln(p, T.ln[4], T.ln[5]);                                // norm3
@@ -729,6 +731,7 @@ struct Fwd : FwdBase {
         TBlock& T = L.tb[0];
         FfTailParams q;
         q.ln = ln; q.lnp = lnp; q.ln_eps = 1e-5f; q.csd = T.lnf_csd; q.wgg = T.wgg; q.wff2 = T.wff2; q.bff2 = T.bff2; q.t = t; q.wpo = L.w16[1];
+        if (chain_tail) { q.a16 = ao; q.wo = T.wo2; q.bo = T.bo2; q.ln_gamma = T.ln[4]; }     // t += ao Wo2^T + bo2 first (attention.py:213)
         q.epi = p;
         if (!dry && !rc) ok(launch_ff_tail(q, s));
       } else {
@@ -891,6 +894,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     f.st_head_on = e_sh ? atoi(e_sh) != 0 : st_head_;
     const char* e_sm = getenv("SDMI_ST_MID");
     f.st_mid_on = e_sm ? atoi(e_sm) != 0 : st_head_;
+    const char* e_st = getenv("SDMI_ST_TAIL");
+    f.st_tail_on = e_st ? atoi(e_st) != 0 : ff_tail_;
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);

@@ -113,6 +113,23 @@ def ff_tail(ln16, part, eps, csd, wgg, wff2, bff2, t, wpo3, bpo, x_in, out_f32, 
                                           wff2.data_ptr(), bff2.data_ptr(), t.data_ptr(), _s()))
 
 
+def st_tail(a16, wo16, bo, t, ln_gamma, eps, csd, wgg, wff2, bff2, wpo3, bpo, x_in, out_f32, B, ntok, out_f16=None, gn=None):
+    """attn2's out-projection -> GEGLU -> FF-out -> proj_out as one launch (sdmi_k_st_tail): t += a16 Wo^T + bo in place, then
+    out = x_in + proj_out(t + FF(norm3(t)))."""
+    C_ = a16.shape[1]
+    d = _lib.IGemmDesc()
+    d.c0 = C_; d.lda0 = C_; d.B, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride = B, ntok, 1, ntok, 1, 1, 1
+    d.w = wpo3.data_ptr(); d.N = C_; d.mode = 0; d.split16 = 1; d.splitk = 1; d.tile = -1; d.dma = -1
+    d.bias = _lib.ptr(bpo); d.residual = x_in.data_ptr(); d.ldr = x_in.stride(0)
+    d.out_f32 = out_f32.data_ptr(); d.out_f16 = _lib.ptr(out_f16); d.ldo = out_f32.stride(0)
+    if gn:
+        d.gn_n = len(gn)
+        for i, (acc, cpg, cbase) in enumerate(gn):
+            d.gn_acc[i] = acc.data_ptr(); d.gn_cpg[i] = cpg; d.gn_cbase[i] = cbase
+    _lib.check(_lib.load().sdmi_k_st_tail(C.byref(d), a16.data_ptr(), wo16.data_ptr(), bo.data_ptr(), t.data_ptr(), ln_gamma.data_ptr(),
+                                          float(eps), csd.data_ptr(), wgg.data_ptr(), wff2.data_ptr(), bff2.data_ptr(), _s()))
+
+
 def st_head(x, gn_gamma, gn_beta, gn_eps, w_in3, b_in, t, ln_gamma, ln_eps, wqkv, cs, dn, q, k, vt, B, ntok, heads, dh):
     """GroupNorm-apply -> proj_in -> q | k | v as one launch (sdmi_k_st_head).  x [B * ntok, C] fp32; w_in3 = pack_split3(proj_in weight);
     wqkv [3C, C] fp16; (cs, dn) = ln_fold_prep(wqkv, C, norm1 weight, norm1 bias); t [M, C] fp32, q / k [B * heads, ntok, dh],

@@ -55,7 +55,8 @@ def _ff_tail_case(B, ntok, seed):
     wpo3 = K.pack_split3(d(wpo))
     torch.cuda.synchronize()
     return dict(B=B, ntok=ntok, M=M, C=C_, t=t, ln16=ln16, part=part, wp=wp, cs=cs, dn=dn, csd=csd, wff2=d(wff2), bff2=d(bff2), wpo3=wpo3,
-                bpo=d(bpo), x_in=d(x_in), gamma=gamma, beta=beta, wgg=wgg, bgg=bgg, wpo=wpo)
+                bpo=d(bpo), x_in=d(x_in), gamma=gamma, beta=beta, wgg=wgg, bgg=bgg, wpo=wpo, ao=d(ao), wo2=d(wo2), bo2=d(bo2), t_prev=d(t_prev),
+                dgamma=d(gamma))
 
 
 def _three_launches(c, gn=None, want_copy=True):
@@ -129,6 +130,44 @@ def test_ff_tail_repeats_bit_identically_next_to_other_work():
         out = torch.full((c['M'], c['C']), float('nan'), device=DEV)
         K.ff_tail(c['ln16'], c['part'], 1e-5, c['csd'], c['wp'], c['wff2'], c['bff2'], c['t'], c['wpo3'], c['bpo'], c['x_in'], out, 2, 4096)
         assert torch.equal(out, out0), (i, float((out - out0).abs().max()))
+
+
+@pytest.mark.parametrize('B,ntok', [(2, 4096), (1, 64), (3, 128), (2, 9216)])
+def test_st_tail_is_bit_identical_to_the_four_launches(B, ntok):
+    """attn2's out-projection in front of the chain (sdmi_k_st_tail): the token stream (updated in place) and the output are the bits of
+    the igemm launch + the three launches; statistics as in the ff_tail test."""
+    c = _ff_tail_case(B, ntok, 4321 + ntok)
+    M, C_ = c['M'], c['C']
+    mk = lambda: torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+    acc_a, ref_a = mk(), mk()
+    out_ref, copy_ref, _, _, _ = _three_launches(c, gn=[(ref_a, 10, 0)])
+    t = c['t_prev'].clone()
+    out = torch.full((M, C_), float('nan'), device=DEV)
+    copy = torch.full((M, C_), float('nan'), dtype=torch.float16, device=DEV)
+    K.st_tail(c['ao'], c['wo2'], c['bo2'], t, c['dgamma'], 1e-5, c['csd'], c['wp'], c['wff2'], c['bff2'], c['wpo3'], c['bpo'], c['x_in'], out,
+              B, ntok, out_f16=copy, gn=[(acc_a, 10, 0)])
+    torch.cuda.synchronize()
+    eq = [torch.equal(t, c['t']), torch.equal(out, out_ref), torch.equal(copy, copy_ref)]
+    print(f'[st_tail vs launches] t / out / copy equal: {eq}; max diffs {float((t - c["t"]).abs().max()):.3e} '
+          f'{float((out - out_ref).abs().max()):.3e}', flush=True)
+    assert all(eq), eq
+    s, ss = K.gn_acc_sums(acc_a)
+    s0, ss0 = K.gn_acc_sums(ref_a)
+    assert torch.allclose(s, s0, rtol=1e-6, atol=1e-3) and torch.allclose(ss, ss0, rtol=1e-6, atol=1e-3)
+
+
+def test_st_tail_repeats_bit_identically_next_to_other_work():
+    c = _ff_tail_case(2, 4096, 11)
+    out_ref, _, _, _, _ = _three_launches(c, gn=None, want_copy=False)
+    junk = torch.empty(96 << 20, device=DEV)          # 384 MB > the 256 MB Infinity Cache
+    for i in range(30):
+        if i % 2:
+            junk.fill_(float(i))
+        t = c['t_prev'].clone()
+        out = torch.full((c['M'], c['C']), float('nan'), device=DEV)
+        K.st_tail(c['ao'], c['wo2'], c['bo2'], t, c['dgamma'], 1e-5, c['csd'], c['wp'], c['wff2'], c['bff2'], c['wpo3'], c['bpo'], c['x_in'], out,
+                  2, 4096)
+        assert torch.equal(t, c['t']) and torch.equal(out, out_ref), (i, float((out - out_ref).abs().max()))
 
 
 def _st_head_case(B, ntok, seed, heads=8):
