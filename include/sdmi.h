@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 14
+#define SDMI_ABI_VERSION 15
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -259,6 +259,16 @@ int sdmi_k_ff_tail(const sdmi_igemm_desc* proj_out, const void* ln_f16, const fl
  * weight (its bias lives in csd).  The same bits as sdmi_k_igemm (bias, residual = t, out_f32 = t, f16_scale, lnp_out) -> sdmi_k_ff_tail. */
 int sdmi_k_st_tail(const sdmi_igemm_desc* proj_out, const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma,
                    float ln_eps, const float* csd, const void* wgg_f16, const void* wff2_f16, const float* bff2, void* stream);
+/* ResBlock in_layers / out_layers as ONE launch (ABI 15; csrc/gnconv.hip; ldm/modules/diffusionmodules/openaimodel.py:201-204, 225-231,
+ * util.py:199-216): out = conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) + bias (+ rowvec, + residual) for N = 320 output channels, a workgroup per
+ * 32 pixels of an image row x all output channels (the input halo is normalised once per workgroup).
+ * conv: the descriptor of the stride-1 3x3 convolution (ksize 3, c0 + c1 + c2 = Cin input channels, B, Hin = Hout, Win = Wout % 32 == 0,
+ * w = sdmi_k_pack_conv, N = 320, mode 0, bias / rowvec / residual / out_f32 / out_f16 / gn_* as for sdmi_k_igemm) -- a0 .. a2 are not read;
+ * x0 [B * H * W][c0], x1 [..][c1] (or NULL, c1 = 0) fp32 NHWC, 256 <= c0 + c1 <= 960, c0 % 64 == 0; gn_ws: sdmi_k_groupnorm_ws_floats(B, H * W)
+ * floats of scratch (the statistics are computed by a statistics launch in front).  The same bits as sdmi_k_groupnorm (silu, fp16 out) ->
+ * sdmi_k_igemm with splitk = 1. */
+int sdmi_k_gn_conv3(const sdmi_igemm_desc* conv, const float* x0, const float* x1, int c0, int c1, float* gn_ws, int64_t gn_ws_floats,
+                    const float* gn_gamma, const float* gn_beta, float gn_eps, void* stream);
 /* GroupNorm-apply -> proj_in -> q | k | v of a SpatialTransformer as ONE launch (ABI 13; csrc/rowchain.hip; ldm/modules/attention.py:254-256,
  * 212, 170-176): t = proj_in(GroupNorm(x)) + b_in (fp32 [M][C], M = B * ntok), q | k | v = norm1(t) Wqkv^T scattered per head
  * (q, k: [B * heads][ntok][dh] fp16, vt: [B * heads][dh][ntok_pad] fp16) for C = 320 channels, a workgroup per 32 token rows.

@@ -288,6 +288,22 @@ int sdmi_k_st_tail(const sdmi_igemm_desc* proj_out, const void* a_f16, const voi
   q.wgg = (const f16*)wgg_f16; q.wff2 = (const f16*)wff2_f16; q.bff2 = bff2; q.t = t; q.wpo = (const f16*)proj_out->w;
   return launch_ff_tail(q, (hipStream_t)stream);
 }
+int sdmi_k_gn_conv3(const sdmi_igemm_desc* conv, const float* x0, const float* x1, int c0, int c1, float* gn_ws, int64_t gn_ws_floats,
+                    const float* gn_gamma, const float* gn_beta, float gn_eps, void* stream) {
+  SDMI_CHECK(conv && x0 && gn_ws && gn_gamma && gn_beta, "gn_conv3: null argument");
+  GnConvParams q;
+  if (igemm_params_of(conv, q.epi)) return -1;
+  const int B = q.epi.B;
+  SDMI_CHECK(gn_ws_floats >= gn_acc_words(B) * 2, "groupnorm workspace too small");
+  SDMI_HIP_OK(hipMemsetAsync(gn_ws, 0, gn_acc_words(B) * sizeof(long long), (hipStream_t)stream));
+  GroupNormParams g;
+  g.x0 = x0; g.c0 = c0; g.x1 = x1; g.c1 = c1; g.B = B; g.HW = q.epi.Hout * q.epi.Wout; g.gamma = gn_gamma; g.beta = gn_beta; g.eps = gn_eps;
+  g.stats_only = 1; g.acc = (long long*)gn_ws;
+  if (launch_groupnorm(g, (hipStream_t)stream)) return -1;
+  q.x0 = x0; q.x1 = x1; q.c0 = c0; q.c1 = c1; q.gn_acc = (const long long*)gn_ws; q.gn_gamma = gn_gamma; q.gn_beta = gn_beta; q.gn_eps = gn_eps;
+  q.w = (const f16*)conv->w;
+  return launch_gn_conv3(q, (hipStream_t)stream);
+}
 int sdmi_k_st_head(const float* x, float* gn_ws, int64_t gn_ws_floats, const float* gn_gamma, const float* gn_beta, float gn_eps,
                    const void* w_in3, const float* b_in, float* t, const float* ln_gamma, float ln_eps, const void* wqkv_f16,
                    const float* lnf_cs, const float* lnf_d, void* q, void* k, void* vt, int B, int ntok, int ntok_pad, int heads, int dh,

@@ -336,6 +336,21 @@ int launch_st_head(const StHeadParams& p, hipStream_t stream);
 // (ln_gamma = norm2 weight, wqkv = Wq [C][C], lnf_cs / lnf_d [C]; k / vt / x / gn_* unused)     attention.py:212-213, 170, 191-192
 int launch_st_mid(const StHeadParams& p, hipStream_t stream);
 
+// ResBlock in_layers / out_layers as one launch (gnconv.hip): out = conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) + bias (+ row vector, + residual)
+//   openaimodel.py:201-204, 225-231; util.py:199-216.  A workgroup owns 32 pixels x ALL 320 output channels: the halo is normalised once.
+struct GnConvParams {
+  const float* x0 = nullptr; const float* x1 = nullptr; int c0 = 0, c1 = 0;      // fp32 NHWC sources (channel concat; c0 % 64 == 0)
+  const long long* gn_acc = nullptr;        // GroupNorm statistics accumulators of cat(x0, x1) (GroupNormParams::acc, complete before the launch)
+  const float* gn_gamma = nullptr; const float* gn_beta = nullptr; float gn_eps = 1e-5f;
+  const f16* w = nullptr;                   // packed conv weights [320][9 Cin] (launch_pack_conv_weight)
+#ifdef SDMI_RC_TIMING
+  long long* dbg = nullptr;                 // timing build only: [workgroups][16] cycle stamps
+#endif
+  IGemmParams epi;                          // the convolution's descriptor (conv3(): B, H, W, N = 320, K = 9 Cin) with its epilogue fields
+};
+bool gn_conv3_supported(int B, int H, int W, int c0, int c1, int Cout);
+int launch_gn_conv3(const GnConvParams& p, hipStream_t stream);
+
 // Flash attention over per-head layouts produced by EPI_HEADS
 struct AttnParams {
   const f16* q = nullptr;    // [BH][nq][d]

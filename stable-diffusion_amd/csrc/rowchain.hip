@@ -52,6 +52,24 @@ constexpr int RC_UNIT = RC_UROWS * 128;        // 20 KB: 160 rows x 64 k fp16
 constexpr int RC_UPIECES = RC_UNIT / 1024;     // LDS-DMA instructions per unit (20, all issued by the loader wave)
 constexpr int RC_NS = 4;                       // ring depth (3, 4 and 5 measured the same)
 constexpr int RC_NLD_DEFAULT = 2;
+// The PREFETCH wave (template argument PF; gnconv.hip has the measurements): inside a UNet call the weights are HBM-cold, the workgroups of
+// an XCD stream the same unit at the same time and a CU keeps only ~256 lines in flight, so first touches of the L2 (~1300 cycles against
+// ~700 for a hit) set the pace of the ring.  The workgroups of an XCD (slot = blockIdx / 8 of gridDim / 8) share the job: behind the barrier
+// of unit g each touches its 1 / nslots of the 160 lines of unit g + RC_PFD (one dword per 32 bytes, into a dead corner of LDS, never waited
+// for): together they have pulled the whole unit into their L2 before anybody streams it, at ~5 lines per workgroup and unit.
+constexpr int RC_PFD = 24;
+#if defined(__HIP_DEVICE_COMPILE__)
+// this lane's line of a unit for the prefetch wave: row offset inside the unit's 160 weight rows (64 w + [0, 32) of compute wave w) and the
+// 32-byte sector, or -1
+__device__ __forceinline__ int rc_pf_row(int lane, int* sector) {
+  const int ntiles = gridDim.x, bid = blockIdx.x;
+  const bool ok = (ntiles & 7) == 0;
+  const int nslots = ok ? max(ntiles >> 3, 10) : 1, slot = ok ? (bid >> 3) : 1;
+  const int idx = slot + (lane >> 2) * nslots;
+  *sector = (lane & 3) * 32;
+  return (slot < nslots && idx < 160) ? 64 * (idx >> 5) + (idx & 31) : -1;
+}
+#endif
 
 // ---- the flat schedule of weight units of ff_tail_kernel<320>, in consumption order ------------------------------------------
 constexpr int FT_C = 320, FT_KT = FT_C / 64, FT_HID = 4 * FT_C, FT_NCHUNK = 4;
@@ -111,8 +129,8 @@ __device__ __forceinline__ void rc_static_for(F&& f) { rc_static_for_impl(std::m
 // HEAD: the out-projection of attn2 in front (FfTailParams::a16 ...): t += a16 Wo^T + bo in place, the LayerNorm-folded GEGLU operand strip
 // fp16(gamma3 * t) and the row statistics stay in LDS -- st_head_kernel's KIND 1 first stage (the same bits as the igemm launch it replaces:
 // bias, residual = t, out_f32 = t, f16_scale, lnp_out)                 attention.py:213 (x = attn2(norm2(x), context) + x: to_out, :191-192)
-template <int C, int NLD, int ABL = 0, int NS = RC_NS, bool HEAD = false>
-__global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTailParams rp) {
+template <int C, int NLD, int ABL = 0, int NS = RC_NS, bool HEAD = false, bool PF = false>
+__global__ void __launch_bounds__(RC_NTC + 64 * NLD + (PF ? 64 : 0)) ff_tail_kernel(const FfTailParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C; the unit table is generated for it");
   constexpr int KT = C / 64;                          // k-tiles of a K = C GEMM piece (5)
@@ -124,7 +142,8 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
   constexpr int RING = NS * RC_UNIT;
   constexpr int OFF_XA = RING, OFF_XG = OFF_XA + XBYTES, OFF_AUX = OFF_XG + 2 * XBYTES, OFF_TAB = OFF_AUX + 2 * AUXB;
   constexpr int OFF_LNP = OFF_TAB + RC_ROWS * 8;      // (HEAD) [row][C / 32] {sum, sum of squares} of the token stream's 32-column blocks
-  constexpr int LDS_TOTAL = OFF_LNP + (HEAD ? RC_ROWS * (C / 32) * 8 : 0);
+  constexpr int OFF_PF = OFF_LNP + (HEAD ? RC_ROWS * (C / 32) * 8 : 0);       // 256 B nobody reads (the prefetch wave's destination)
+  constexpr int LDS_TOTAL = OFF_PF + (PF ? 256 : 0);
   constexpr int LSTR = 64;                            // (HEAD) row pitch (floats) of the out-projection's epilogue slabs: five 32 x 64 fp32 = the two GEGLU strips
   static_assert(RC_NWC * 32 * LSTR * 4 <= 2 * XBYTES, "the epilogue slabs live in the (still unused) hidden-chunk strips");
   static_assert(NLD == 1 || NLD == 2, "loader waves");
@@ -152,6 +171,34 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) ff_tail_kernel(const FfTail
   const IGemmParams& ep = rp.epi;
   constexpr int OOB = (int)0x80000000;
 
+  if (PF && wave_u == RC_NWC + NLD) {
+    // =============================== the prefetch wave (see RC_PFD) ================================================================
+    const __amdgpu_buffer_rsrc_t rs_gg = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wgg, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ff = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wff2, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_po = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wpo, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_wo = __builtin_amdgcn_make_buffer_rsrc((void*)(HEAD ? rp.wo : rp.wgg), 0, OOB, 0x00020000);
+    int sector;
+    const int prow = rc_pf_row(lane, &sector);
+    const int v_c = prow >= 0 ? prow * (C * 2) + sector : OOB, v_h = prow >= 0 ? prow * (HID * 2) + sector : OOB,
+              v_3 = prow >= 0 ? prow * (3 * C * 2) + sector : OOB;
+    auto touch = [&](int u) {
+      if (u >= NU) return;
+      const int soff = __builtin_amdgcn_readfirstlane(kFtTab.soff[TB + u]);
+      const int sel = __builtin_amdgcn_readfirstlane(kFtTab.sel[TB + u]);
+      const __amdgpu_buffer_rsrc_t rs = sel == 0 ? rs_gg : (sel == 1 ? rs_ff : (sel == 2 ? rs_po : rs_wo));
+      const int vo = (sel == 0 || sel == 3) ? v_c : (sel == 1 ? v_h : v_3);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(smem + OFF_PF), 4, vo, soff, 0, 0);
+    };
+    for (int u = NS - 1; u < RC_PFD; ++u) touch(u);
+    for (int g = 0; g < NU; ++g) {                      // (the loaders' barriers, one for one)
+      if (HEAD && g == FT_BLK) asm volatile("s_barrier" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      touch(g + RC_PFD);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    return;
+  }
   if (wave_u >= RC_NWC) {
     // =============================== the loader waves ==============================================================================
     const int lw = wave_u - RC_NWC;                     // this loader's pieces: p = lw, lw + NLD, ... (loader 0 also brings the small operands)
@@ -514,8 +561,8 @@ constexpr ShUnitTab sh_make_tab() {
 }
 __device__ const ShUnitTab kShTab = sh_make_tab();
 
-template <int C, int NLD, int KIND, int NS = RC_NS>
-__global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHeadParams rp) {
+template <int C, int NLD, int KIND, int NS = RC_NS, bool PF = false>
+__global__ void __launch_bounds__(RC_NTC + 64 * NLD + (PF ? 64 : 0)) st_head_kernel(const StHeadParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C");
   static_assert(NLD == 1 || NLD == 2, "loader waves");
@@ -528,7 +575,8 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   constexpr int OFF_GTAB = OFF_XN + XBYTES;           // {mean, rstd} of the sample's 32 GroupNorm groups
   constexpr int OFF_LTAB = OFF_GTAB + 32 * 8;         // {mean, rstd} of the strip's rows (norm1)
   constexpr int OFF_LNP = OFF_LTAB + RC_ROWS * 8;     // [row][C / 32] {sum, sum of squares} of the token stream's 32-column blocks
-  constexpr int LDS_TOTAL = OFF_LNP + RC_ROWS * (C / 32) * 8;
+  constexpr int OFF_PF = OFF_LNP + RC_ROWS * (C / 32) * 8;        // 256 B nobody reads (the prefetch wave's destination)
+  constexpr int LDS_TOTAL = OFF_PF + (PF ? 256 : 0);
   constexpr int LSTR = 64;                            // row pitch (floats) of the epilogue slabs: five 32 x 64 fp32 slabs = the two proj_in strips
   static_assert(RC_NWC * 32 * LSTR * 4 <= 2 * XBYTES, "the epilogue slabs live in the (dead) proj_in operand strips");
   constexpr int LPIECES = RC_UPIECES / NLD, LD_WAIT = LPIECES * (NS - 2);
@@ -548,6 +596,31 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD) st_head_kernel(const StHead
   const int m0 = blockIdx.x * RC_ROWS;
   constexpr int OOB = (int)0x80000000;
 
+  if (PF && wave_u == RC_NWC + NLD) {
+    // =============================== the prefetch wave (see RC_PFD) ================================================================
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc((void*)rp.w_in, 0, OOB, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_qkv = __builtin_amdgcn_make_buffer_rsrc((void*)rp.wqkv, 0, OOB, 0x00020000);
+    int sector;
+    const int prow = rc_pf_row(lane, &sector);
+    const int v_c = prow >= 0 ? prow * (C * 2) + sector : OOB, v_3 = prow >= 0 ? prow * (3 * C * 2) + sector : OOB;
+    auto touch = [&](int u) {
+      if (u >= NU) return;
+      const int soff = __builtin_amdgcn_readfirstlane(kShTab.soff[KIND][u]);
+      const int sel = __builtin_amdgcn_readfirstlane(kShTab.sel[KIND][u]);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(sel == 0 ? rs_in : rs_qkv, (__attribute__((address_space(3))) void*)(smem + OFF_PF), 4,
+                                               (KIND == 0 && sel == 0) ? v_3 : v_c, soff, 0, 0);
+    };
+    for (int u = NS - 1; u < RC_PFD; ++u) touch(u);
+    asm volatile("s_barrier" ::: "memory");             // X0
+    for (int g = 0; g < NU; ++g) {                      // (the loaders' barriers, one for one)
+      if (g == NU1) asm volatile("s_barrier" ::: "memory");
+      asm volatile("s_barrier" ::: "memory");
+      touch(g + RC_PFD);
+    }
+    wait_vmcnt<0>();
+    asm volatile("s_barrier" ::: "memory");
+    return;
+  }
   if (wave_u >= RC_NWC) {
     // =============================== the loader waves (see ff_tail_kernel) =========================================================
     const int lw = wave_u - RC_NWC;
@@ -911,11 +984,17 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
 #define RC_ABL(NLD) switch (abl) { case 1: RC_LAUNCH(NLD, 1); break; case 2: RC_LAUNCH(NLD, 2); break; case 3: RC_LAUNCH(NLD, 3); break; default: RC_LAUNCH(NLD, 0); break; }
   if (nld == 1) { RC_ABL(1) } else { RC_ABL(2) }
 #else
-  if (head) {
-    if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1, 0, RC_NS, true>), grid, dim3(RC_NTC + 64), 0, stream, q);
-    else hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 128), 0, stream, q);
-  } else if (nld_env == 1) hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
-  else hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  const int pf = env_int("SDMI_CHAIN_PF", 1);           // the prefetch wave (read per launch: A/B)
+  if (nld_env == 1) {
+    if (head) hipLaunchKernelGGL((ff_tail_kernel<320, 1, 0, RC_NS, true>), grid, dim3(RC_NTC + 64), 0, stream, q);
+    else hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  } else if (pf) {
+    if (head) hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, true, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+    else hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, false, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+  } else {
+    if (head) hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 128), 0, stream, q);
+    else hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  }
 #endif
   SDMI_HIP_OK(hipGetLastError());
   return 0;
@@ -949,6 +1028,7 @@ int launch_st_head(const StHeadParams& p, hipStream_t stream) {
   q.dbg = g_sh_dbg;
 #endif
   if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 0>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else if (env_int("SDMI_CHAIN_PF", 1)) hipLaunchKernelGGL((st_head_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
   else hipLaunchKernelGGL((st_head_kernel<320, 2, 0>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
@@ -969,6 +1049,7 @@ int launch_st_mid(const StHeadParams& p, hipStream_t stream) {
   q.dbg = g_sh_dbg;
 #endif
   if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else if (env_int("SDMI_CHAIN_PF", 1)) hipLaunchKernelGGL((st_head_kernel<320, 2, 1, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
   else hipLaunchKernelGGL((st_head_kernel<320, 2, 1>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());
   return 0;

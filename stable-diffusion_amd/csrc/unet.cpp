@@ -463,6 +463,7 @@ struct Fwd : FwdBase {
   bool st_head_on = false;      // ... and SpatialTransformer heads (UNet::st_head_; SDMI_ST_HEAD, read per call)
   bool st_mid_on = false;       // ... and the out-projection of attn1 with attn2's to_q (SDMI_ST_MID)
   bool st_tail_on = false;      // ... and the out-projection of attn2 in front of the tail's chain launch (SDMI_ST_TAIL)
+  bool gn_conv_on = false;      // ResBlock GroupNorm + SiLU + conv3x3 as one launch where a workgroup can own all output columns (gnconv.hip; SDMI_GN_CONV)
   // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
   bool fuse_ctx_q = false;
@@ -510,7 +511,24 @@ struct Fwd : FwdBase {
     Act out = make_act(P<float>((size_t)M * Cout), Cout, H, W, true);
     Act hact = make_act(h, Cout, H, W, true);
     f16* a2 = nullptr; int gn2_applied = 0;
-    {
+    // in_layers / out_layers as ONE launch each (gnconv.hip: 32 pixels x all 320 output channels per workgroup, the halo normalised once):
+    // the 64 x 64 level of SD v1.  (in_layers only without a skip convolution: that one reads raw fp16 copies the GroupNorm launch writes.)
+    const bool gc1 = gn_conv_on && !fold1 && Cin == Cout && gn_conv3_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
+    const bool gc2 = gn_conv_on && !fold2 && gn_conv3_supported(B, H, W, Cout, 0, Cout);
+    auto gn_conv = [&](const Act& a0, const Act* a1, const float* gamma, const float* beta, const f16* w, IGemmParams& e) {
+      GnConvParams g;
+      g.gn_acc = groupnorm(a0, a1, gamma, beta, 1e-5f, 1, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
+      g.x0 = a0.p; g.c0 = a0.C; g.x1 = a1 ? a1->p : nullptr; g.c1 = a1 ? a1->C : 0;
+      g.gn_gamma = gamma; g.gn_beta = beta; g.gn_eps = 1e-5f; g.w = w; g.epi = e;
+      if (!dry && !rc) ok(launch_gn_conv3(g, s));
+    };
+    if (gc1) {
+      IGemmParams p = conv3(nullptr, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
+      p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = emb_ld;
+      p.out_f32 = h; p.ldo = Cout;
+      attach_gn_targets(p, hact);
+      gn_conv(x0, x1, L.f32[0], L.f32[1], L.w16[0], p);
+    } else {
       IGemmParams p;
       if (fold1) {
         p = conv3_gn(x0, x1, L.f32[0], L.f32[1], L.w16[0], Cout, raw, raw_lo);    // (+ the skip conv's raw hi | lo operand)
@@ -523,7 +541,7 @@ struct Fwd : FwdBase {
       p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = emb_ld;
       p.out_f32 = h; p.ldo = Cout;
       attach_gn_targets(p, hact);          // statistics of out_layers' GroupNorm come out of this epilogue
-      if (!fold2) {
+      if (!fold2 && !gc2) {
         // ... or, where this conv ends up split along K (8x8, 16x16, the concat blocks of 32x32), GroupNorm + SiLU are applied by
         // its split-K reduction: a2 = the conv2 operand comes straight out of it (IGemmParams::pgn_*; gn2_applied says so)
         a2 = S<f16>((size_t)M * Cout);
@@ -538,7 +556,14 @@ struct Fwd : FwdBase {
       if (fold1) gemm(p); else gemm_side(p);
       residual = out.p;
     }
-    {
+    if (gc2) {
+      IGemmParams p = conv3(nullptr, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
+      if (Cin != Cout && !fold1) join_side();
+      p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
+      attach_gn_targets(p, out);
+      attach_f16_copy(p, out);
+      gn_conv(hact, nullptr, L.f32[3], L.f32[4], L.w16[1], p);
+    } else {
       IGemmParams p;
       if (fold2) {
         p = conv3_gn(hact, nullptr, L.f32[3], L.f32[4], L.w16[1], Cout, nullptr, nullptr);
@@ -896,6 +921,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     f.st_mid_on = e_sm ? atoi(e_sm) != 0 : st_head_;
     const char* e_st = getenv("SDMI_ST_TAIL");
     f.st_tail_on = e_st ? atoi(e_st) != 0 : ff_tail_;
+    const char* e_gc = getenv("SDMI_GN_CONV");
+    f.gn_conv_on = e_gc ? atoi(e_gc) != 0 : false;       // (opt-in: bit-identical, 36 us against 41 us with hot operands, +4 us per launch inside a UNet call -- profiles/gn_conv3_r05.txt)
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);

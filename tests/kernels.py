@@ -130,6 +130,31 @@ def st_tail(a16, wo16, bo, t, ln_gamma, eps, csd, wgg, wff2, bff2, wpo3, bpo, x_
                                           float(eps), csd.data_ptr(), wgg.data_ptr(), wff2.data_ptr(), bff2.data_ptr(), _s()))
 
 
+def gn_conv3(x0, x1, gamma, beta, eps, wp, N, out_f32, bias=None, rowvec=None, residual=None, out_f16=None, gn=None):
+    """conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) as ONE launch (sdmi_k_gn_conv3).  x0 / x1: fp32 [B, H, W, C]; wp = pack_conv_weight(w);
+    out_f32 [B * H * W, N]."""
+    B, H, W, c0 = x0.shape
+    c1 = 0 if x1 is None else x1.shape[3]
+    d = _lib.IGemmDesc()
+    d.c0 = c0 + c1; d.lda0 = c0 + c1
+    d.B, d.Hin, d.Win, d.Hout, d.Wout, d.ksize, d.stride, d.up = B, H, W, H, W, 3, 1, 0
+    d.w = wp.data_ptr(); d.N = N; d.mode = 0; d.splitk = 1; d.tile = -1; d.dma = -1
+    d.bias = _lib.ptr(bias)
+    if rowvec is not None:
+        d.rowvec = rowvec.data_ptr(); d.ld_rowvec = rowvec.stride(0)
+    if residual is not None:
+        d.residual = residual.data_ptr(); d.ldr = residual.stride(0)
+    d.out_f32 = out_f32.data_ptr(); d.out_f16 = _lib.ptr(out_f16); d.ldo = out_f32.stride(0)
+    if gn:
+        d.gn_n = len(gn)
+        for i, (acc, cpg, cbase) in enumerate(gn):
+            d.gn_acc[i] = acc.data_ptr(); d.gn_cpg[i] = cpg; d.gn_cbase[i] = cbase
+    n = _lib.load().sdmi_k_groupnorm_ws_floats(B, H * W)
+    ws = torch.empty((n,), dtype=torch.float32, device=x0.device)
+    _lib.check(_lib.load().sdmi_k_gn_conv3(C.byref(d), x0.data_ptr(), _lib.ptr(x1), c0, c1, ws.data_ptr(), n, gamma.data_ptr(),
+                                           beta.data_ptr(), float(eps), _s()))
+
+
 def st_head(x, gn_gamma, gn_beta, gn_eps, w_in3, b_in, t, ln_gamma, ln_eps, wqkv, cs, dn, q, k, vt, B, ntok, heads, dh):
     """GroupNorm-apply -> proj_in -> q | k | v as one launch (sdmi_k_st_head).  x [B * ntok, C] fp32; w_in3 = pack_split3(proj_in weight);
     wqkv [3C, C] fp16; (cs, dn) = ln_fold_prep(wqkv, C, norm1 weight, norm1 bias); t [M, C] fp32, q / k [B * heads, ntok, dh],
