@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, 'csrc')
 EXTRA = os.environ.get('SDMI_CXXFLAGS', '').split()
 LIB = os.path.join(HERE, os.environ.get('SDMI_LIB_OUT', 'libsdmi.so'))
 OBJ = os.path.join(HERE, 'build' if os.path.basename(LIB) == 'libsdmi.so' else 'build_' + os.path.splitext(os.path.basename(LIB))[0])
-SOURCES = ['igemm.hip', 'conv3halo.hip', 'gemm_split16.hip', 'igemm5.hip', 'rowchain.hip', 'gnconv.hip', 'range.hip', 'attn.hip', 'attn_ctx.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
+SOURCES = ['igemm_t1.hip', 'igemm_t0.hip', 'igemm_t2.hip', 'igemm.hip', 'conv3halo.hip', 'gemm_split16.hip', 'igemm5.hip', 'rowchain.hip', 'gnconv.hip', 'range.hip', 'attn.hip', 'attn_ctx.hip', 'norm.hip', 'small.hip', 'sampler.hip', 'unet.cpp', 'vae.cpp', 'clip.cpp', 'api.cpp', 'prof.cpp']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-munsafe-fp-atomics', '-Wall', '-Wno-unused-function',
          '-Wno-unused-variable']
 

@@ -10,6 +10,10 @@ namespace sdmi {
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream);
+// the generic kernel's tile shapes, instantiated in three translation units (igemm_t0 / t1 / t2.hip)
+int launch_generic_tile_g0(int tile, const IGemmParams& p, bool dma, int splitk, hipStream_t stream);
+int launch_generic_tile_g1(int tile, const IGemmParams& p, bool dma, int splitk, hipStream_t stream);
+int launch_generic_tile_g2(int tile, const IGemmParams& p, bool dma, int splitk, hipStream_t stream);
 
 static int env_int(const char* name, int dflt) {
   const char* v = getenv(name);

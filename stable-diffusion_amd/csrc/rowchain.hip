@@ -57,7 +57,10 @@ constexpr int RC_NLD_DEFAULT = 2;
 // ~700 for a hit) set the pace of the ring.  The workgroups of an XCD (slot = blockIdx / 8 of gridDim / 8) share the job: behind the barrier
 // of unit g each touches its 1 / nslots of the 160 lines of unit g + RC_PFD (one dword per 32 bytes, into a dead corner of LDS, never waited
 // for): together they have pulled the whole unit into their L2 before anybody streams it, at ~5 lines per workgroup and unit.
-constexpr int RC_PFD = 24;
+#ifndef SDMI_RC_PFD
+#define SDMI_RC_PFD 24
+#endif
+constexpr int RC_PFD = SDMI_RC_PFD;                    // (build-time A/B: tools/build_variant.sh rowchain.hip -DSDMI_RC_PFD=n; 12 / 24 / 48 measured)
 #if defined(__HIP_DEVICE_COMPILE__)
 // this lane's line of a unit for the prefetch wave: row offset inside the unit's 160 weight rows (64 w + [0, 32) of compute wave w) and the
 // 32-byte sector, or -1
