@@ -30,7 +30,10 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
-GEMM_CLASSES = ('igemm', 'conv3halo', 'gemm_split16', 'ff_tail')      # profiler class-name prefixes of the GEMM family (one MFMA core + shared epilogue)
+# profiler class-name prefixes of the GEMM family (one MFMA core + shared epilogue); the row-strip chain kernels (rowchain.hip: st_head = GroupNorm-apply
+# + proj_in + q|k|v, st_mid = out-projection + to_q, st_tail / ff_tail = out-projection + GEGLU + FF-out + proj_out, gnconv3 = GroupNorm + conv3x3)
+# run several of the reference's GEMMs per launch: their algorithmic flops are the sum of those GEMMs'
+GEMM_CLASSES = ('igemm', 'conv3halo', 'gemm_split16', 'ff_tail', 'st_tail', 'st_head', 'st_mid', 'gnconv3')
 MFMA_PEAK_TFLOPS = 2500.0     # dense fp16/bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md
 HBM_PEAK_GBS = 8000.0
 UNET_GFLOP = {64: 1606.5, 96: 4296.2}     # one UNet call, CFG batch 2, latent 64x64 / 96x96
@@ -62,7 +65,8 @@ def build_gpu_model(device, seed=0, vae_kind='hip', vae_parts=1):
         vae = AutoencoderKLHIP(SD_V1_VAE_DDCONFIG, None, 4, parts=vae_parts).to(device).eval()
         randomize_vae_(vae, seed)
     else:                       # A/B: the decoder on stock PyTorch-ROCm (fp16 autocast), what north_star started from
-        from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        from vae_torch import AutoencoderKLDecoder      # (tools/vae_torch.py: not part of the package)
         torch.manual_seed(seed)
         vae = AutoencoderKLDecoder().to(device).eval()
     return ld, unet, vae
@@ -258,7 +262,7 @@ def traffic_pass(out_json=None, keep_dir=None, also=None):
 
     def family(name):
         for key, fam in (('igemm_kernel', 'igemm_family'), ('igemm5_kernel', 'igemm_family'), ('conv3halo_kernel', 'igemm_family'),
-                         ('conv3halo_gn_kernel', 'igemm_family'), ('gemm_split16_kernel', 'igemm_family'), ('ff_tail_kernel', 'igemm_family'),
+                         ('conv3halo_gn_kernel', 'igemm_family'), ('gemm_split16_kernel', 'igemm_family'), ('ff_tail_kernel', 'igemm_family'), ('st_head_kernel', 'igemm_family'), ('gn_conv3_kernel', 'igemm_family'),
                          ('attn', 'attention'),
                          ('splitk_reduce', 'splitk_reduce'), ('gn_apply', 'groupnorm'), ('gn_stats', 'groupnorm'),
                          ('layernorm', 'layernorm')):
@@ -502,7 +506,7 @@ def main():
                     r['ms_events'] = r['ms']
                     r['ms'] = r['ms'] * ev_scale
                 fam = [r for r in table if r['name'].startswith(GEMM_CLASSES)]
-                dom = {'name': 'igemm_kernel / conv3halo_kernel / gemm_split16_kernel / ff_tail_kernel (the GEMM family: one MFMA core + shared epilogue, all tile instantiations)',
+                dom = {'name': 'igemm_kernel / conv3halo_kernel / gemm_split16_kernel / ff_tail_kernel / st_head_kernel (the GEMM family: one MFMA core + shared epilogue, all tile instantiations; the row-strip chain kernels run 2-4 of the reference GEMMs per launch)',
                        'launches': sum(r['launches'] for r in fam), 'ms': sum(r['ms'] for r in fam),
                        'flops': sum(r['flops'] for r in fam), 'flops_exec': sum(r.get('flops_exec', r['flops']) for r in fam),
                        'bytes': sum(r['bytes'] for r in fam)}

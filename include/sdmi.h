@@ -44,6 +44,10 @@ typedef struct sdmi_unet_cfg {
 
 const char* sdmi_last_error(void);
 int sdmi_abi_version(void);
+/* 1 if the library was built with -DSDMI_EXPERIMENTS: the kernels that lost their same-box A/Bs (the GroupNorm-folding halo conv / split-fp16
+ * GEMM / split-K reduction, the five-wave tile 22, attention with the to_q projection inside, the ping-pong attention schedule) and their
+ * environment knobs are compiled in.  The product library (0) has neither; their entry points fail with a message that says so. */
+int sdmi_has_experiments(void);
 
 /* ---- UNet handle: replaces instantiate_from_config(unet_config) + load_state_dict ----------------------- */
 /* UNetModel.__init__, openaimodel.py:443-692 */

@@ -91,6 +91,7 @@ _SIGS = {
     'sdmi_clip_finalize': (C.c_int, [c_ptr]),
     'sdmi_clip_workspace_bytes': (C.c_int64, [c_ptr, C.c_int, C.c_int]),
     'sdmi_clip_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr]),
+    'sdmi_has_experiments': (C.c_int, []),
     'sdmi_k_igemm': (C.c_int, [C.POINTER(IGemmDesc), c_ptr]),
     'sdmi_k_ff_tail': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sdmi_k_gn_conv3': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_float, c_ptr]),

@@ -37,6 +37,13 @@ extern "C" {
 
 const char* sdmi_last_error(void) { return g_err.c_str(); }
 int sdmi_abi_version(void) { return SDMI_ABI_VERSION; }
+int sdmi_has_experiments(void) {
+#ifdef SDMI_EXPERIMENTS
+  return 1;
+#else
+  return 0;
+#endif
+}
 
 int sdmi_unet_create(const sdmi_unet_cfg* cfg, sdmi_unet** out) {
   SDMI_CHECK(cfg && out, "null argument");

@@ -513,6 +513,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+#ifdef SDMI_EXPERIMENTS      // (bit-identical, measured 12 % slower at d = 40 in round 4: profiles/experiments_r04.txt)
 // ---- ping-pong variant of attn_dma_kernel for 8-wave workgroups (two waves per SIMD) ------------------------------------------
 // Same arithmetic, operand layouts and LDS-DMA ring as attn_dma_kernel -- per wave the very same instruction sequence on the same
 // values, so the results are bit-identical -- but the two waves of a SIMD no longer run in lock-step.  attn_dma_kernel has one
@@ -763,6 +764,14 @@ __global__ void __launch_bounds__(512) attn_pp_kernel(const AttnParams p) {
   }
 #endif  // __HIP_DEVICE_COMPILE__
 }
+#endif  // SDMI_EXPERIMENTS
+
+// A/B knobs of the experiments build (SDMI_CXXFLAGS=-DSDMI_EXPERIMENTS): the product library reads none of them
+#ifdef SDMI_EXPERIMENTS
+#define SDMI_EXP_ENV(name, def) (getenv(name) ? atoi(getenv(name)) : (def))
+#else
+#define SDMI_EXP_ENV(name, def) (def)
+#endif
 
 template <int D>
 int launch_d(const AttnParams& p, hipStream_t stream) {
@@ -773,8 +782,8 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
     const int slices = cdiv(p.nq, 32);
     // (same-box A/B, profiles/ab_*_r01.txt: 4 waves beat 8 up to 1024 queries -- more, smaller workgroups)
     nw = (slices >= 8 && p.nq > 1024) ? 8 : (slices >= 4 ? 4 : 2);
-    static const int env_small = getenv("SDMI_ATTN_NW_LE1K") ? atoi(getenv("SDMI_ATTN_NW_LE1K")) : 0;   // A/B knobs
-    static const int env_big = getenv("SDMI_ATTN_NW_GT1K") ? atoi(getenv("SDMI_ATTN_NW_GT1K")) : 0;
+    static const int env_small = SDMI_EXP_ENV("SDMI_ATTN_NW_LE1K", 0);   // A/B knobs
+    static const int env_big = SDMI_EXP_ENV("SDMI_ATTN_NW_GT1K", 0);
     if (env_small > 0 && p.nq <= 1024) nw = env_small;
     if (env_big > 0 && p.nq > 1024) nw = env_big;
   }
@@ -782,7 +791,7 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
   static const std::string pname_long = std::string("attn_d") + std::to_string(D) + "_self";
   static const std::string pname_short = std::string("attn_d") + std::to_string(D) + "_ctx";
   ProfScope ps((p.nkv >= 256 ? pname_long : pname_short).c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
-  static const int use_v1 = getenv("SDMI_ATTN_V1") ? atoi(getenv("SDMI_ATTN_V1")) : 0;     // A/B: the register-staged kernel
+  static const int use_v1 = SDMI_EXP_ENV("SDMI_ATTN_V1", 0);     // A/B: the register-staged kernel (the product build keeps it for unaligned K / V only)
   constexpr int DNS = (D > 128) ? 3 : 4;                        // LDS-DMA ring depth (D = 160: 3 x 44 KB)
   if (!use_v1 && !p.causal && (p.nkv * D) % 8 == 0) {
     // timing-only ablations (WRONG results: each removes one ingredient of the loop, tools/attn_ablate.py) exist only in a build with
@@ -806,8 +815,10 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
         }
       }
 #endif
+#ifdef SDMI_EXPERIMENTS
     } else if (nw == 8 && p.pingpong && DNS >= 4) {
       if constexpr (DNS >= 4) hipLaunchKernelGGL((attn_pp_kernel<D, DNS>), grid, dim3(512), 0, stream, p);
+#endif
     } else if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
     else if (nw == 4) hipLaunchKernelGGL((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
     else hipLaunchKernelGGL((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);
@@ -831,10 +842,9 @@ int launch_attention(const AttnParams& p, hipStream_t stream) {
 }
 static int launch_attention_impl(const AttnParams& p_in, hipStream_t stream) {
   AttnParams p = p_in;
-  static const int env_prio = getenv("SDMI_ATTN_PRIO") ? atoi(getenv("SDMI_ATTN_PRIO")) : 0;      // A/B knob (bit-identical)
+  static const int env_prio = SDMI_EXP_ENV("SDMI_ATTN_PRIO", 0);      // A/B knob (bit-identical)
   p.prio = env_prio;
-  const char* e_pp = getenv("SDMI_ATTN_PP");          // (read per launch: the tests flip it) 8-wave launches on attn_pp_kernel
-  p.pingpong = e_pp ? atoi(e_pp) : 0;
+  p.pingpong = SDMI_EXP_ENV("SDMI_ATTN_PP", 0);       // (read per launch: the tests flip it) 8-wave launches on attn_pp_kernel
   SDMI_CHECK(p.BH > 0 && p.nq > 0 && p.nkv > 0 && p.heads > 0 && p.BH % p.heads == 0, "bad attention shape");
   SDMI_CHECK(p.nkv_pad % 8 == 0 && p.nkv_pad >= p.nkv, "nkv_pad must be a multiple of 8 and >= nkv");
   SDMI_CHECK(!p.causal || p.nq == p.nkv, "causal attention needs nq == nkv");

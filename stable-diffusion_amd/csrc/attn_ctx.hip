@@ -24,6 +24,7 @@
 // with vmcnt(0) (the two kinds do not retire through one in-order queue, profiles/gn_fold_r03.txt).
 #include "igemm_dev.h"
 
+#ifdef SDMI_EXPERIMENTS      // (to_q inside the cross-attention kernel: measured slower in round 3, profiles/experiments_r03.txt)
 namespace sdmi {
 namespace {
 
@@ -328,3 +329,11 @@ int launch_attention_ctx(const AttnCtxParams& p, hipStream_t stream) {
 }
 
 }  // namespace sdmi
+#else
+namespace sdmi {
+bool attention_ctx_supported(int, int, int) { return false; }
+int launch_attention_ctx(const AttnCtxParams&, hipStream_t) {
+  return fail("attention with the to_q projection inside (attn_ctx.hip) is an experiment: build with SDMI_CXXFLAGS=-DSDMI_EXPERIMENTS");
+}
+}  // namespace sdmi
+#endif

@@ -269,6 +269,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_kernel(const 
 }
 
 
+#ifdef SDMI_EXPERIMENTS      // (the GroupNorm-folding halo conv: bit-identical, measured slower at every site in round 3, profiles/gn_fold_r03.txt)
 // compile-time loop: f(std::integral_constant<int, I>) for I in [I0, N)
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -704,6 +705,7 @@ __global__ void __launch_bounds__(WARPS_M* WARPS_N * 64) conv3halo_gn_kernel(con
 #endif  // __HIP_DEVICE_COMPILE__
 }
 
+#endif  // SDMI_EXPERIMENTS
 }  // namespace
 
 // halo-staged 3x3 convolution: supported iff stride 1, pad 1, no upsampling, power-of-two width 16..64 and tiles of whole
@@ -771,6 +773,9 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
 // -- an octet of channels then spans at most two groups --, at most 4 images per tile and 8 spare rows in the halo buffer for
 // the {mean, rstd} table)
 bool halo_gn_supported(const IGemmParams& p, int bm) {
+#ifndef SDMI_EXPERIMENTS
+  return false;
+#endif
   if (!halo_supported(p, bm)) return false;
   const int Cin = p.c0 + p.c1, W = p.Wout, HW = p.Hout * p.Wout;
   if (p.c2 != 0 || Cin % 64 != 0 || p.c0 % 64 != 0 || (Cin / 32) < 8) return false;
@@ -781,6 +786,7 @@ bool halo_gn_supported(const IGemmParams& p, int bm) {
          (int64_t)p.B * HW * std::max(p.c0, p.c1) * 4 < ((int64_t)1 << 31) - 65536;
 }
 
+#ifdef SDMI_EXPERIMENTS
 template <int BM, int BN, int WARPS_M, int WARPS_N, int NS>
 int launch_halo_gn_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   SDMI_CHECK(halo_gn_supported(p, BM), "GroupNorm-folding halo conv requested for an unsupported shape");
@@ -835,7 +841,12 @@ int launch_halo_gn_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   return 0;
 }
 
+#endif  // SDMI_EXPERIMENTS
+
 bool gn_fold_conv_supported(int B, int H, int W, int c0, int c1, int N) {
+#ifndef SDMI_EXPERIMENTS
+  return false;      // (product build: the kernel is not compiled in)
+#else
   // Opt-in (SDMI_FUSE_GN_CONV=1).  Same-box A/B, round 3 (profiles/gn_fold_r03.txt): 6.97 ms per UNet call with the folding kernel
   // at its heuristic sites, 8.04 ms with it at every site, against 6.50 ms for GroupNorm-apply launches + the tuned LDS-DMA
   // convolutions: every one of the N / BN column tiles of a convolution repeats the normalisation (+ SiLU: two quarter-rate
@@ -849,10 +860,14 @@ bool gn_fold_conv_supported(int B, int H, int W, int c0, int c1, int N) {
   for (int bm : {256, 128})
     if (bm <= std::max(p.M, 128) && halo_gn_supported(p, bm)) return true;
   return false;
+#endif
 }
 
 // tile ids 14 .. 17 of the table in igemm.hip (kTiles); p.xf0 != NULL selects the GroupNorm-folding kernel
 int launch_halo_gn_tile(int tile, const IGemmParams& p, int splitk, hipStream_t stream) {
+#ifndef SDMI_EXPERIMENTS
+  return fail("the GroupNorm-folding halo conv (conv3halo_gn_kernel) is an experiment: build with SDMI_CXXFLAGS=-DSDMI_EXPERIMENTS");
+#else
   switch (tile) {
     case 14: return launch_halo_gn_cfg<256, 64, 4, 2, 5>(p, splitk, stream);
     case 15: return launch_halo_gn_cfg<256, 128, 4, 2, 3>(p, splitk, stream);
@@ -860,6 +875,7 @@ int launch_halo_gn_tile(int tile, const IGemmParams& p, int splitk, hipStream_t 
     case 17: return launch_halo_gn_cfg<128, 128, 2, 2, 5>(p, splitk, stream);
     default: return fail("not a halo-staged conv tile id");
   }
+#endif
 }
 
 // tile ids 14 .. 17 of the table in igemm.hip (kTiles)

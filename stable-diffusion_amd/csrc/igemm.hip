@@ -166,6 +166,7 @@ __device__ __forceinline__ f32x4 quad_transpose(const f32x4 v, int sub) {
   const f32x4 r = {r0, r1, r2, r3};                               // r[k] = element (row sub, column (sub - k) & 3)
   return f32x4{pick4(r, sub & 3), pick4(r, (sub - 1) & 3), pick4(r, (sub - 2) & 3), pick4(r, (sub - 3) & 3)};
 }
+#ifdef SDMI_EXPERIMENTS      // (bit-identical, 15 launches fewer, measured slower in round 4: profiles/splitk_slabs_r04.txt)
 // Split-K reduction + GroupNorm(32) (+ SiLU) of the result in ONE launch (IGemmParams::pgn_*; ResBlock conv1 -> out_layers'
 // GroupNorm -> SiLU, openaimodel.py:225-231, at the levels where conv1 is split: 8x8, 16x16, the concat blocks of 32x32).
 // Workgroup (g, b) owns group g of sample b: HW rows x cpg = N / 32 channels.  Thread t handles the 16-byte quads t, t + 1024, ...
@@ -284,6 +285,8 @@ __global__ void __launch_bounds__(1024) splitk_reduce_gn_kernel(IGemmParams p, i
     }
   }
 }
+
+#endif  // SDMI_EXPERIMENTS
 
 // ---- reduction over register-order slabs (IGemmParams::slab_tiled) -------------------------------------------------------
 // a quad's statistics partials as splitk_reduce_kernel forms them with one row per thread: channels j < gsplit belong to the first
@@ -426,6 +429,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_tiled_heads_kernel(IGemmPar
 
 int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   SDMI_CHECK(nsplit >= 1 && nsplit <= 16 && p.N % 4 == 0 && p.splitk_ws, "splitk_reduce: bad arguments");
+#ifdef SDMI_EXPERIMENTS
   if (const int maxq = reduce_gn_maxq(p, nsplit)) {       // the consuming GroupNorm (+ SiLU) inside the reduction: see the kernel
     const unsigned long long magic_qpr = div_magic(p.N / 128);
     const double mn = (double)p.M * p.N;
@@ -446,6 +450,7 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     if (range_check_enabled() && range_scan("GroupNorm fp16 output (split-K reduction)", p.pgn_out, (int64_t)p.M * p.N, stream)) return -1;
     return 0;
   }
+#endif
   if (p.slab_tiled) {                  // register-order slabs: one thread per slab quad, whole tiles (padding rows / columns masked)
     const int64_t quads = (int64_t)cdiv(p.M, p.slab_bm) * cdiv(p.N, p.slab_bn) * (p.slab_bm * p.slab_bn / 4);
     SDMI_CHECK(quads % 256 == 0 && quads / 256 < (1ll << 31) && p.slab_wm > 0 && p.slab_wn > 0, "tiled split-K slabs: bad geometry");
@@ -522,6 +527,11 @@ static const TileCfg kTiles[SDMI_NUM_TILES] = {
     {64, 160, 1, 5, 5},    // 22  5 waves, 2x1 per wave, 140 KB
 };
 static inline bool tile_is5(int t) { return t == 22; }
+#ifdef SDMI_EXPERIMENTS
+constexpr bool kExperiments = true;
+#else
+constexpr bool kExperiments = false;      // product build: tile 22, the GroupNorm-folding kernels and the GroupNorm-applying split-K reduction are not compiled in
+#endif
 static inline bool tile_is_halo(int t) { return t >= 14 && t <= 17; }
 static inline bool tile_tn_even(int t) { return (kTiles[t].bn / kTiles[t].wn / 32) % 2 == 0; }
 
@@ -615,7 +625,7 @@ static std::vector<TuneChoice> tune_candidates(const IGemmParams& p, bool can_sp
     if (tile_is_halo(t) && !halo_supported(p, c.bm)) continue;
     if (p.xf0 && (!tile_is_halo(t) || !halo_gn_supported(p, c.bm))) continue;     // GroupNorm-folding conv: halo tiles only
     if (p.split16 && !split16_tile_supported(t)) continue;                         // split-fp16 GEMM: its own instantiations
-    if (tile_is5(t) && (p.up || p.split16 || p.xf0 || p.N % c.bn != 0)) continue;   // five-wave tile: whole 160-column tiles, plain gathers
+    if (tile_is5(t) && (!kExperiments || p.up || p.split16 || p.xf0 || p.N % c.bn != 0)) continue;   // five-wave tile: whole 160-column tiles, plain gathers
     // never chosen by any of the round-2 collection runs (profiles/tune_candidates_r02.txt): the 2-stage twins of the
     // 3-stage tiles, 128x128 / 256x128 with 2 stages, and the 64x256 / 256x64 4-wave tiles -- fewer candidates = more
     // samples per candidate
@@ -810,7 +820,7 @@ int launch_igemm(const IGemmParams& p, const IGemmTune& tune, hipStream_t stream
                                           : (sk == 1 || (ws_ok && nkt / sk >= 4 && (halo || (sk != 5 && sk != 10)) &&
                                                          (!halo || (nkt / 9) % sk == 0)));
         if (split_ok && (p.mode != EPI_GEGLU || tile_tn_even(tt)) && (!halo || halo_supported(p, kTiles[tt].bm)) &&
-            (!tile_is5(tt) || (!p.up && !p.split16 && p.N % kTiles[tt].bn == 0)) &&
+            (!tile_is5(tt) || (kExperiments && !p.up && !p.split16 && p.N % kTiles[tt].bn == 0)) &&
             (!gn_fold || (halo && halo_gn_supported(p, kTiles[tt].bm))) && (!p.split16 || split16_tile_supported(tt))) {
           tile = tt; splitk = sk;
         }

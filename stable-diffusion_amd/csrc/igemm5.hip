@@ -17,6 +17,7 @@
 // choice.  The 16-byte chunks are XOR-swizzled with (row >> 1) & 7 on the source side, as in the generic kernel.
 #include "igemm_dev.h"
 
+#ifdef SDMI_EXPERIMENTS      // (lost its in-situ tuning A/B in round 3: never chosen; kept as the record of what was measured)
 namespace sdmi {
 namespace {
 
@@ -280,3 +281,10 @@ int launch_igemm5_tile(int tile, const IGemmParams& p, int splitk, hipStream_t s
 }
 
 }  // namespace sdmi
+#else
+namespace sdmi {
+int launch_igemm5_tile(int, const IGemmParams&, int, hipStream_t) {
+  return fail("tile 22 (five-wave 64 x 160 tile, igemm5.hip) is an experiment: build with SDMI_CXXFLAGS=-DSDMI_EXPERIMENTS");
+}
+}  // namespace sdmi
+#endif

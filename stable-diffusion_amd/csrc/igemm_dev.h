@@ -695,6 +695,9 @@ static int reduce_rows_per_block(const IGemmParams& p) {
 // -0.01 ms per UNet call against the row-major reduce + GroupNorm-apply launches on a fast box, +0.04 ... +0.17 ms against the
 // register-order reduce + GroupNorm-apply launches (mid / slow box: 24 us per launch there).
 static int reduce_gn_maxq(const IGemmParams& p, int nsplit) {
+#ifndef SDMI_EXPERIMENTS
+  return 0;                                         // (product build: splitk_reduce_gn_kernel is not compiled in)
+#endif
   const int on = env_int("SDMI_REDUCE_GN", 0);      // (read per launch: the tests flip it between two forwards)
   const int hw = p.Hout * p.Wout;
   if (!on || !p.pgn_out || !p.pgn_gamma || !p.pgn_beta || p.mode != EPI_PLAIN || nsplit < 2 || nsplit > 16) return 0;

@@ -500,8 +500,12 @@ struct Fwd : FwdBase {
     const size_t mark = scratch.off;
     // GroupNorm + SiLU folded into the halo staging of the 3x3 convs where the geometry allows (every level of SD v1)
     // (SDMI_FUSE_GN_WHICH: bit 0 in_layers, bit 1 out_layers; SDMI_FUSE_GN_W: only at this width -- bisecting knobs)
+#ifdef SDMI_EXPERIMENTS
     static const int fold_which = getenv("SDMI_FUSE_GN_WHICH") ? atoi(getenv("SDMI_FUSE_GN_WHICH")) : 3;
     static const int fold_w = getenv("SDMI_FUSE_GN_W") ? atoi(getenv("SDMI_FUSE_GN_W")) : 0;
+#else
+    constexpr int fold_which = 3, fold_w = 0;     // (gn_fold_conv_supported() is false in the product build: no fold site)
+#endif
     const bool fold_here = fold_w == 0 || fold_w == W;
     const bool fold1 = (fold_which & 1) && fold_here && gn_fold_conv_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
     const bool fold2 = (fold_which & 2) && fold_here && gn_fold_conv_supported(B, H, W, Cout, 0, Cout);
@@ -923,11 +927,13 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     f.st_tail_on = e_st ? atoi(e_st) != 0 : ff_tail_;
     const char* e_gc = getenv("SDMI_GN_CONV");
     f.gn_conv_on = e_gc ? atoi(e_gc) != 0 : false;       // (opt-in: bit-identical, 36 us against 41 us with hot operands, +4 us per launch inside a UNet call -- profiles/gn_conv3_r05.txt)
+#ifdef SDMI_EXPERIMENTS      // (kernels of the experiments build: attn_ctx.hip, gemm_split16_gn_kernel)
     const char* e_ctx = getenv("SDMI_ATTN_CTX_FUSED");
     f.fuse_ctx_q = e_ctx && atoi(e_ctx) != 0;
     if (const char* e_md = getenv("SDMI_ATTN_CTX_MAXD")) f.fuse_ctx_maxd = atoi(e_md);
     const char* e_gp = getenv("SDMI_GN_PROJ_FOLD");
     f.gn_proj_fold = (e_gp && atoi(e_gp) != 0) && f.ln_fold_on;       // (the kernel has no LayerNorm post-op launch: it rides on the fold)
+#endif
   }
   if (side_stream_ && !dry && !prof_enabled()) {      // (the per-launch profiler times launches on one stream)
     if (!side_) {

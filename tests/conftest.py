@@ -21,6 +21,9 @@ def _usable_cores():
 
 def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+    config.addinivalue_line('markers', 'experiments: exercises a kernel that lost its same-box A/B and is only compiled with -DSDMI_EXPERIMENTS '
+                            '(SDMI_CXXFLAGS=-DSDMI_EXPERIMENTS SDMI_LIB_OUT=libsdmi_exp.so python stable-diffusion_amd/build.py; '
+                            'SDMI_LIB_PATH=.../libsdmi_exp.so pytest -m "gpu and experiments"); skipped against the product library')
     import torch
     # the GPU boxes expose 256 logical CPUs under a 16-CPU cgroup quota: torch's default thread count thrashes there
     torch.set_num_threads(min(32, _usable_cores()))
@@ -38,11 +41,16 @@ def pytest_collection_modifyitems(config, items):
     """GPU tests must not silently pass on a GPU-less host: they are skipped there unless selected with -m gpu,
     in which case a missing GPU is an error (the product path has no fallback)."""
     import torch
-    if torch.cuda.is_available():
+    if not torch.cuda.is_available():
+        for item in items:
+            if 'gpu' in item.keywords:
+                item.add_marker(pytest.mark.skip(reason='no GPU on this host'))
         return
-    for item in items:
-        if 'gpu' in item.keywords:
-            item.add_marker(pytest.mark.skip(reason='no GPU on this host'))
+    from stable_diffusion_amd import _lib
+    if not _lib.load().sdmi_has_experiments():
+        for item in items:
+            if 'experiments' in item.keywords:
+                item.add_marker(pytest.mark.skip(reason='the product libsdmi.so is built without -DSDMI_EXPERIMENTS'))
 
 
 @pytest.fixture(scope='session')

@@ -251,6 +251,7 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
     (3, 8, 8, 256, 128, 2, 2, 1, False),          # smallest legal width: 4 channels per group
     (2, 16, 16, 320, 256, 0, -1, 3, False),       # auto split / auto tile: applied or not, the launcher says which
 ])
+@pytest.mark.experiments
 @pytest.mark.parametrize('tiled', ['1', '0'])
 def test_igemm_splitk_reduce_applies_groupnorm(B, H, W, C, N, splitk, tile, ksize, resid, tiled, monkeypatch):
     """GroupNorm(32) + SiLU of a split-K conv's output applied by its reduction (splitk_reduce_gn_kernel, sdmi_igemm_desc::pgn_*):
@@ -881,6 +882,7 @@ def _gn_fold_inputs(B, H, W, c0, c1, N, seed):
     return x0, x1, gamma, beta, w, bias, rowvec, resid
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('case', GN_FOLD_CASES, ids=[c[0] for c in GN_FOLD_CASES])
 def test_conv3_gn_fold(case):
     """ResBlock in_layers / out_layers: conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) + bias + emb + residual
@@ -999,6 +1001,7 @@ def test_layernorm_folded_into_consumer(mode, ptile, ctile):
 FIVE_WAVE_CASES = [c for c in CONV_CASES if not c[9]]        # (the five-wave tile has no upsampling gather)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('case', FIVE_WAVE_CASES, ids=[c[0] for c in FIVE_WAVE_CASES])
 @pytest.mark.parametrize('splitk', [1, 3])
 def test_igemm_five_wave_tile(case, splitk):
@@ -1034,6 +1037,7 @@ def test_igemm_five_wave_tile(case, splitk):
     assert K.report(f'igemm5 {name} split{splitk} f16', out16, ref2, 6e-3) < 6e-3
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('B,H,W,C,N,ksize', [(2, 64, 64, 320, 320, 3), (2, 64, 64, 320, 320, 1), (2, 32, 32, 640, 640, 3), (2, 64, 64, 320, 960, 1)])
 def test_igemm_five_wave_tile_sd_shapes(B, H, W, C, N, ksize):
     """the shapes tile 22 is for (64x64 / 32x32 levels of SD v1), with the GroupNorm statistics of the output from the epilogue:
@@ -1060,6 +1064,7 @@ def test_igemm_five_wave_tile_sd_shapes(B, H, W, C, N, ksize):
     assert torch.allclose(q0, (xs * xs).sum(dim=(1, 3)), rtol=1e-6, atol=1e-2)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('d,heads,nq,nkv,B', [(40, 8, 4096, 77, 2), (80, 8, 1024, 77, 2), (160, 8, 256, 77, 2), (160, 8, 64, 77, 2),
                                               (40, 8, 100, 77, 1), (80, 8, 64, 128, 1), (160, 8, 33, 5, 3), (40, 8, 256, 96, 2)])
 @pytest.mark.parametrize('fold', [False, True])
@@ -1109,6 +1114,7 @@ def test_attention_ctx_fused_q(d, heads, nq, nkv, B, fold, monkeypatch):
     assert e1 < 4e-3 and e1 <= 1.5 * e2 + 3e-4, (e1, e2)
 
 
+@pytest.mark.experiments
 @pytest.mark.parametrize('d,heads,nq,nkv', [(40, 8, 4096, 4096), (40, 8, 4096, 4000), (80, 8, 1024, 1024), (64, 4, 512, 77), (40, 8, 2304, 2304),
                                             (128, 2, 300, 130), (32, 4, 256, 64)])
 def test_attention_pingpong_is_bit_identical(d, heads, nq, nkv, monkeypatch):

@@ -387,6 +387,7 @@ def test_refuses_cpu_and_bad_config():
 
 
 @pytest.mark.gpu
+@pytest.mark.experiments
 @pytest.mark.parametrize('cfg_name,B,h,w', [('sdv1', 2, 32, 32), ('sdv1', 2, 64, 64)])
 def test_groupnorm_inside_proj_in_is_bit_identical(cfg_name, B, h, w, monkeypatch):
     """SpatialTransformer: proj_in(norm(x)) (attention.py:254-255) with the GroupNorm applied inside the split-fp16 GEMM while it
@@ -405,6 +406,7 @@ def test_groupnorm_inside_proj_in_is_bit_identical(cfg_name, B, h, w, monkeypatc
 
 
 @pytest.mark.gpu
+@pytest.mark.experiments
 @pytest.mark.parametrize('case', ['sdv1_8x8', 'sdv1_16x16', 'sdv1_64x64', 'sdv1_b6_16x16', 'tiny_16x16'])
 def test_groupnorm_inside_the_splitk_reduction_is_bit_identical(case, golden_dir, monkeypatch):
     """ResBlock conv1 -> GroupNorm + SiLU -> conv2 (openaimodel.py:225-231) where conv1 is split along K: the reduction applies

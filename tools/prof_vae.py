@@ -12,7 +12,8 @@ import torch  # noqa: E402
 
 from stable_diffusion_amd import AutoencoderKLHIP, _lib  # noqa: E402
 from stable_diffusion_amd.synthetic import SD_V1_VAE_DDCONFIG, randomize_vae_  # noqa: E402
-from stable_diffusion_amd.vae_torch import AutoencoderKLDecoder  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+from vae_torch import AutoencoderKLDecoder  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1
 dev = torch.device('cuda')
