@@ -324,12 +324,25 @@ __device__ __forceinline__ TiledQuad tiled_quad(const IGemmParams& p, int q, int
 // out = sum_s slab[s] + bias + rowvec[batch] + residual: the arithmetic (and with one row per thread the statistics partials) of
 // splitk_reduce_kernel, value by value.  A block = 256 consecutive slab quads = four GEMM waves' share of one 32-row slab each, so a
 // wave's rows lie inside one sample: the statistics are combined per wave in LDS and leave as one atomic set per (wave, group).
-__global__ void __launch_bounds__(256) splitk_reduce_tiled_kernel(IGemmParams p, int nsplit) {
-  __shared__ unsigned long long s_gn[2][4][32][GN_WORDS];        // [target][wave][group]
+//
+// COOP: the reduction also APPLIES the GroupNorm (+ SiLU) whose statistics it has just produced (IGemmParams::pgn_*: ResBlock conv1 ->
+// out_layers' GroupNorm -> SiLU -> conv2 at the levels where conv1 is split, openaimodel.py:225-231) -- the GroupNorm-apply launch behind it
+// disappears.  The statistics are global, so the workgroups meet at a grid barrier between producing and using them: every thread waits for
+// its statistics atomics to be acknowledged, one ticket per workgroup on a counter, a bounded spin (coherent loads) until all tickets are in;
+// the launcher only takes this path when every workgroup of the grid is resident at once (<= 256 workgroups of 1024 threads).  Then the (sample, group) totals
+// are folded exactly as norm.hip's apply kernel folds them (gn_mean_rstd over the eight slots) and the quad still sitting in registers is
+// normalised with gn_apply_elem: the same fp16 bits as the two launches.  A spin that runs out (cannot happen with a resident grid) stores
+// NaNs: loud, not a hang.
+// (COOP workgroups are 1024 threads: the tickets of a grid all land on ONE address, and device-scope atomics on one address retire
+// at ~25 ns each -- 640 workgroups of 256 threads spent 16 us at the barrier, profiles/reduce_gn_coop_r05.txt)
+template <bool COOP>
+__global__ void __launch_bounds__(COOP ? 1024 : 256) splitk_reduce_tiled_kernel(IGemmParams p, int nsplit) {
+  constexpr int NWV = COOP ? 16 : 4;                              // waves per workgroup (at most)
+  __shared__ unsigned long long s_gn[2][NWV][32][GN_WORDS];      // [target][wave][group]
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6, NTB = blockDim.x;      // (256 threads, or 128: SDMI_REDUCE_BLOCK)
   const bool gn = p.gn_n > 0;
   if (gn) {
-    for (int i = tid; i < 2 * 4 * 32 * GN_WORDS; i += NTB) (&s_gn[0][0][0][0])[i] = 0ull;
+    for (int i = tid; i < 2 * NWV * 32 * GN_WORDS; i += NTB) (&s_gn[0][0][0][0])[i] = 0ull;
     __syncthreads();
   }
   const TiledQuad t = tiled_quad(p, blockIdx.x * NTB + tid, lane);
@@ -353,7 +366,7 @@ __global__ void __launch_bounds__(256) splitk_reduce_tiled_kernel(IGemmParams p,
   if (p.rowvec) v += rvv;
   if (p.residual) v += resv;
   if (t.valid) {
-    if (p.out_f32) SDMI_ST_F32X4(p.out_f32, (size_t)m * p.ldo + n, v);
+    if (p.out_f32 && (!COOP || p.pgn_keep_f32)) SDMI_ST_F32X4(p.out_f32, (size_t)m * p.ldo + n, v);
     if (p.out_f16) SDMI_ST_F16X4(p.out_f16, (size_t)m * p.ldo + n, (f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]}));
     if (p.out_lo) {
       f16x4 lo;
@@ -377,16 +390,68 @@ __global__ void __launch_bounds__(256) splitk_reduce_tiled_kernel(IGemmParams p,
     }
     __syncthreads();
     const int slot = blockIdx.x & (GN_SLOTS - 1);
-    for (int e = tid; e < p.gn_n * 4 * 32 * GN_WORDS; e += NTB) {
+    for (int e = tid; e < p.gn_n * NWV * 32 * GN_WORDS; e += NTB) {
       const unsigned long long w = (&s_gn[0][0][0][0])[e];
       if (w == 0ull) continue;
-      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, w4 = (e / (GN_WORDS * 32)) % 4, tg = e / (GN_WORDS * 32 * 4);
+      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, w4 = (e / (GN_WORDS * 32)) % NWV, tg = e / (GN_WORDS * 32 * NWV);
       // the sample of that wave's 32-row slab: its first row (lane 0 of the wave would own it)
       if (w4 * 64 >= NTB) continue;
       const TiledQuad t0 = tiled_quad(p, blockIdx.x * NTB + w4 * 64, 0);
       if (t0.m >= p.M) continue;
       const int b = t0.m / HW;
       atomicAdd((unsigned long long*)p.gn_acc[tg] + ((size_t)(b * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, w);
+    }
+  }
+  if constexpr (COOP) {
+    // ---- grid barrier: this workgroup's statistics are in memory, then its ticket; wait for everybody's ----
+    __shared__ int s_ok;
+    __shared__ float2 s_tab[NWV][4];                      // [wave][group - first group of the wave's 32 columns] {mean, rstd}
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int* const cnt = p.splitk_cnt + p.splitk_cnt_ints - 2;              // {tickets, departures}: zero between launches
+    const int nblk = (int)gridDim.x;
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int budget = 1 << 16, seen = 0;
+      while ((seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < nblk && --budget > 0) __builtin_amdgcn_s_sleep(4);
+      s_ok = seen >= nblk;
+      // the last one to leave zeroes the pair for the next launch (launches of a stream do not overlap)
+      if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1) {
+        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    __syncthreads();
+    // ---- {mean, rstd} of the (at most four) groups this wave's 32 columns touch: lanes 8 k .. 8 k + 7 fold the eight slots of group gfirst + k
+    // (norm.hip gn_fold), coherent loads: the totals were written by every XCD ----
+    const int cpg = p.N >> 5;
+    const TiledQuad tw = tiled_quad(p, blockIdx.x * NTB + wv * 64, 0);   // the wave's first quad: first row, first column of its 32 x 32 block
+    const int bw = min(tw.m, p.M - 1) / HW;
+    const int gfirst = fast_div(min(tw.n, p.N - 1), p.gn_magic[0]);
+    if (lane < 32) {
+      const int g = min(gfirst + (lane >> 3), 31), sub = lane & 7;
+      const long long* srcw = (const long long*)p.gn_acc[0] + ((size_t)(bw * 32 + g) * GN_SLOTS + sub) * GN_STRIDE;
+      long long a0 = __hip_atomic_load(srcw, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), a1 = __hip_atomic_load(srcw + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      long long q0 = __hip_atomic_load(srcw + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), q1 = __hip_atomic_load(srcw + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+      for (int o = GN_SLOTS / 2; o >= 1; o >>= 1) {
+        a0 += __shfl_xor(a0, o); a1 += __shfl_xor(a1, o); q0 += __shfl_xor(q0, o); q1 += __shfl_xor(q1, o);
+      }
+      if (sub == 0) {
+        float mu, rs;
+        gn_mean_rstd(a0, a1, q0, q1, (double)cpg * (double)HW, p.pgn_eps, &mu, &rs);
+        s_tab[wv][lane >> 3] = float2{mu, rs};
+      }
+    }
+    __syncthreads();
+    if (t.valid) {
+      // (cpg % 4 == 0: the launcher checked -- a quad lies inside one group)
+      const float2 mr = s_tab[wv][min(fast_div(n, p.gn_magic[0]) - gfirst, 3)];
+      const f32x4 ga = *(const f32x4*)(p.pgn_gamma + n), be = *(const f32x4*)(p.pgn_beta + n);
+      f16x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = s_ok ? (f16)gn_apply_elem(v[j], mr.x, mr.y, ga[j], be[j], p.pgn_silu) : (f16)__builtin_nanf("");
+      SDMI_ST_F16X4(p.pgn_out, (size_t)m * p.N + n, o);
     }
   }
 }
@@ -462,11 +527,32 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
       return 0;
     }
     if (p.gn_n > 0) SDMI_CHECK((p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
-    ProfScope pst("splitk_reduce", 0.0, mn * 4.0 * (nsplit + 1), stream);
+    // the consuming GroupNorm (+ SiLU) applied by the reduction itself, behind a grid barrier (splitk_reduce_tiled_kernel<true>): where
+    // that GroupNorm's statistics come from this very reduction, channels-per-group % 4 == 0 and the whole grid is resident at once
+    // (one workgroup of 1024 threads per CU at most: <= 256 workgroups).  Experiments build, SDMI_REDUCE_GN_COOP=1 (the same bits; measured slower).
+#ifndef SDMI_EXPERIMENTS
+    constexpr bool coop = false;       // (measured slower: a device-scope grid barrier costs 8 - 16 us here, profiles/reduce_gn_coop_r05.txt)
+#else
+    const bool coop = env_int("SDMI_REDUCE_GN_COOP", 0) && p.pgn_out && p.pgn_gamma && p.pgn_beta && p.mode == EPI_PLAIN && p.gn_n == 1 &&
+                      p.gn_cbase[0] == 0 && p.gn_cpg[0] == p.N / 32 && p.N % 128 == 0 && p.N / 32 >= 16 && p.M == p.B * p.Hout * p.Wout &&
+                      (p.Hout * p.Wout) % 32 == 0 && !p.out_f16 && !p.out_lo && !p.ln_out && p.splitk_cnt && p.splitk_cnt_ints >= 2 &&
+                      quads % 1024 == 0 && quads / 1024 <= 256 && (!p.pgn_keep_f32 || (p.out_f32 && p.ldo % 4 == 0));
+#endif
+    ProfScope pst(coop ? "splitk_reduce_gn" : "splitk_reduce", 0.0, coop ? mn * (4.0 * nsplit + 2.0 + (p.pgn_keep_f32 ? 4.0 : 0.0)) : mn * 4.0 * (nsplit + 1), stream);
     // threads per block: 256, or 128 where that still leaves fewer than two blocks per CU (SDMI_REDUCE_BLOCK: 0 auto, 128 / 256 forced; A/B)
     const int rb_env = env_int("SDMI_REDUCE_BLOCK", 256);
     const int rb = (rb_env == 128 || (rb_env == 0 && quads / 256 < 512)) ? 128 : 256;
-    hipLaunchKernelGGL(splitk_reduce_tiled_kernel, dim3((unsigned)(quads / rb)), dim3(rb), 0, stream, p, nsplit);
+#ifdef SDMI_EXPERIMENTS
+    if (coop) {
+      hipLaunchKernelGGL(splitk_reduce_tiled_kernel<true>, dim3((unsigned)(quads / 1024)), dim3(1024), 0, stream, p, nsplit);
+      SDMI_HIP_OK(hipGetLastError());
+      pst.end();
+      if (p.pgn_applied) *p.pgn_applied = 1;
+      if (range_check_enabled() && range_scan("GroupNorm fp16 output (split-K reduction)", p.pgn_out, (int64_t)p.M * p.N, stream)) return -1;
+      return 0;
+    }
+#endif
+    hipLaunchKernelGGL(splitk_reduce_tiled_kernel<false>, dim3((unsigned)(quads / rb)), dim3(rb), 0, stream, p, nsplit);
     SDMI_HIP_OK(hipGetLastError());
     pst.end();
     if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);

@@ -243,6 +243,73 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
     assert (other - outs[0]).abs().max().item() <= 4e-6 * ref.abs().max().item()
 
 
+@pytest.mark.experiments
+@pytest.mark.parametrize('B,H,W,C,N,splitk,tile,ksize,resid', [
+    (2, 8, 8, 1280, 1280, 12, 19, 3, False),      # the 8x8 level: igemm 64x128, 12-way split (ResBlock conv1)
+    (2, 16, 16, 1280, 1280, 10, 15, 3, False),    # 16x16: halo tile 256x128, 640 reduce workgroups
+    (2, 16, 16, 640, 1280, 5, 14, 3, True),       # halo 256x64, with a residual
+    (2, 16, 16, 1280, 640, 4, 6, 3, False),       # 20 channels per group: a wave's 32 columns touch three groups
+    (1, 8, 8, 640, 512, 3, 5, 3, True),           # 16 channels per group (the narrowest accepted), one sample
+])
+def test_igemm_splitk_reduce_groupnorm_behind_a_grid_barrier(B, H, W, C, N, splitk, tile, ksize, resid, monkeypatch):
+    """splitk_reduce_tiled_kernel<COOP> (experiments build, SDMI_REDUCE_GN_COOP=1): the split-K reduction applies the consuming GroupNorm(32) + SiLU itself, behind a grid
+    barrier between producing the statistics and using them (sdmi_igemm_desc::pgn_*; openaimodel.py:225-231 at the split levels).
+    The statistics words must be the integers the plain reduction leaves (SDMI_REDUCE_GN_COOP=0), the fp16 output torch's GroupNorm + SiLU
+    within one rounding, the library's own statistics + apply kernels up to rounding flips (their statistics partition the same values
+    differently; the bit-identity with the two-launch path is checked on whole UNet calls), ten bit-identical repeats."""
+    g = _g(917)
+    a = _rand16((B * H * W, C), g)
+    w = _rand16((N, C, ksize, ksize), g, 1.0 / math.sqrt(ksize * ksize * C))
+    bias = torch.randn(N, generator=g)
+    rowvec = torch.randn(B, N, generator=g)
+    res = torch.randn(B * H * W, N, generator=g) if resid else None
+    gamma = 1.0 + 0.3 * torch.randn(N, generator=g)
+    beta = 0.2 * torch.randn(N, generator=g)
+    v_ref = _nhwc(_conv_ref(a, None, w, B, H, W, ksize, 1, 0)) + bias[None] + rowvec.repeat_interleave(H * W, dim=0)
+    if resid:
+        v_ref = v_ref + res
+    y_ref = F.silu(F.group_norm(v_ref.view(B, H * W, N).permute(0, 2, 1).double(), 32, gamma.double(), beta.double(), 1e-5))
+    y_ref = y_ref.permute(0, 2, 1).reshape(B * H * W, N).float()
+    wp = K.pack_conv_weight(w.float().to(DEV))
+    a_d, bias_d, rv_d = a.to(DEV), bias.to(DEV), rowvec.to(DEV)
+    res_d = res.to(DEV) if resid else None
+    ga_d, be_d = gamma.to(DEV), beta.to(DEV)
+
+    def run(coop, keep):
+        monkeypatch.setenv('SDMI_REDUCE_GN_COOP', coop)
+        o16 = torch.full((B * H * W, N), float('nan'), dtype=torch.float16, device=DEV)
+        o32 = torch.full((B * H * W, N), float('nan'), device=DEV)
+        acc = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
+        applied = K.igemm(a_d, wp, N, B, H, W, H, W, ksize, 1, 0, bias=bias_d, rowvec=rv_d, residual=res_d, out_f32=o32, splitk=splitk,
+                          tile=tile, fused_splitk=True, pgn=(ga_d, be_d, 1e-5, 1, o16, keep), gn=[(acc, N // 32, 0)])
+        torch.cuda.synchronize()
+        return applied, o16, o32, acc
+
+    ap0, _, v2, acc0 = run('0', 0)
+    assert ap0 == 0 and not torch.isnan(v2).any()
+    y2 = K.groupnorm(v2.view(B, H * W, N), None, ga_d, be_d, 1e-5, 1)['f16'].view(B * H * W, N)
+    first = None
+    for rep in range(10):
+        ap, o16, o32, acc = run('1', rep % 2)
+        assert ap == 1
+        assert torch.equal(acc.sum(dim=2), acc0.sum(dim=2))   # the statistics the plain reduction leaves: the slot totals, integer for integer
+        if rep % 2:
+            assert torch.equal(o32, v2)                     # pgn_keep_f32: the reduction's fp32 value, bit for bit
+        else:
+            assert torch.isnan(o32).all()
+        if first is None:
+            first = o16
+        assert torch.equal(o16, first), rep
+    y = first.float().cpu()
+    assert not torch.isnan(y).any()
+    err = (y - y_ref).abs().max().item()
+    print(f'[reduce+gn behind a grid barrier M{B * H * W} N{N} split{splitk} tile{tile}] max-abs vs torch {err:.3e}', flush=True)
+    assert err <= 2e-3 * max(1.0, y_ref.abs().max().item())
+    diff = (first.float() - y2.float()).abs()
+    nflip = int((diff > 0).sum().item())
+    assert diff.max().item() <= 8e-3 and nflip <= 2e-3 * diff.numel() + 2, (diff.max().item(), nflip)
+
+
 @pytest.mark.parametrize('B,H,W,C,N,splitk,tile,ksize,resid', [
     (2, 8, 8, 1280, 1280, 12, 19, 3, False),      # the 8x8 level: igemm 64x128, 12-way split (ResBlock conv1)
     (2, 16, 16, 1280, 1280, 10, 15, 3, False),    # 16x16: halo tile, split at 64-channel chunks

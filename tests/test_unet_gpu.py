@@ -432,6 +432,33 @@ def test_groupnorm_inside_the_splitk_reduction_is_bit_identical(case, golden_dir
     assert torch.equal(e1, e0), float((e1 - e0).abs().max())
 
 
+@pytest.mark.experiments
+@pytest.mark.gpu
+@pytest.mark.parametrize('case', ['sdv1_8x8', 'sdv1_16x16', 'sdv1_64x64', 'sdv1_b6_16x16', 'tiny_16x16'])
+def test_groupnorm_applied_behind_the_reductions_grid_barrier_is_bit_identical(case, golden_dir, monkeypatch):
+    """ResBlock conv1 -> GroupNorm + SiLU -> conv2 (openaimodel.py:225-231) where conv1 is split along K: the reduction applies the
+    GroupNorm itself behind a grid barrier (splitk_reduce_tiled_kernel<COOP>; experiments build, SDMI_REDUCE_GN_COOP=1) instead of leaving it to a GroupNorm-apply
+    launch (SDMI_REDUCE_GN_COOP=0).  The same fp32 value, the same statistics words folded by the same function, the same elementwise
+    function: eps must not change by one bit, three calls in a row."""
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg_name = case.split('_')[0]
+    cfg = CFGS[cfg_name]
+    m, sd = _model(cfg_name, int(z['weight_seed']))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
+    ref = torch.from_numpy(z['eps'])
+    monkeypatch.setenv('SDMI_REDUCE_GN_COOP', '0')
+    e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    monkeypatch.setenv('SDMI_REDUCE_GN_COOP', '1')
+    for rep in range(3):
+        e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(e1, e0), (rep, float((e1 - e0).abs().max()))
+    d1 = float((e1.float().cpu() - ref).abs().max())
+    print(f'[reduce+gn behind a grid barrier {case}] vs reference {d1:.3e}', flush=True)
+    assert d1 <= TOL
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['sdv1_16x16', 'sdv1_64x64', 'sdv1_b6_16x16', 'tiny_16x16'])
 def test_register_order_splitk_slabs_are_bit_identical(case, golden_dir, monkeypatch):
