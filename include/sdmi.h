@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 15
+#define SDMI_ABI_VERSION 16
 
 typedef struct sdmi_unet sdmi_unet;
 
@@ -290,6 +290,12 @@ int sdmi_k_st_head(const float* x, float* gn_ws, int64_t gn_ws_floats, const flo
  * residual = t, out_f32 = t, f16_scale, lnp_out) -> sdmi_k_igemm (mode 2, lnf_*). */
 int sdmi_k_st_mid(const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma, float ln_eps, const void* wq_f16,
                   const float* lnf_cs, const float* lnf_d, void* q, int B, int ntok, int heads, int dh, int C, void* stream);
+/* ... with the cross-attention behind to_q inside the same launch (ABI 16; attention.py:213, 170-193): ctx_k [B * heads][nkv][dh], ctx_vt
+ * [B * heads][dh][nkv_pad] fp16 (the cached context projections, sdmi_k_igemm mode 2), scale = dh^-1/2, ao_out [B * ntok][C] fp16 = the attention
+ * output rows (q is not written).  dh = 40, nkv <= 128.  The same bits as sdmi_k_st_mid -> sdmi_k_attention. */
+int sdmi_k_st_mid_ctx(const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma, float ln_eps, const void* wq_f16,
+                      const float* lnf_cs, const float* lnf_d, const void* ctx_k, const void* ctx_vt, int nkv, int nkv_pad, float scale, void* ao_out,
+                      int B, int ntok, int heads, int dh, int C, void* stream);
 /* cs[n] = sum_k gamma[k] * w[n][k], d[n] = sum_k beta[k] * w[n][k] (+ bias[n]) over the PACKED fp16 weights w [N][ldw]
  * (first K columns of a row): the column terms of a GEMM that folds LayerNorm(gamma, beta) of its input rows */
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,

@@ -95,6 +95,8 @@ _SIGS = {
     'sdmi_k_igemm': (C.c_int, [C.POINTER(IGemmDesc), c_ptr]),
     'sdmi_k_ff_tail': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sdmi_k_gn_conv3': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, C.c_int, C.c_int, c_ptr, C.c_int64, c_ptr, c_ptr, C.c_float, c_ptr]),
+    'sdmi_k_st_mid_ctx': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_float, c_ptr,
+                                    C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, c_ptr]),
     'sdmi_k_st_tail': (C.c_int, [C.POINTER(IGemmDesc), c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'sdmi_k_st_mid': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_float, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
                                 C.c_int, c_ptr]),
@@ -158,7 +160,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 15:
+        if lib.sdmi_abi_version() != 16:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -336,6 +336,17 @@ int sdmi_k_st_mid(const void* a_f16, const void* wo_f16, const float* bo, float*
   p.M = B * ntok; p.B = B; p.ntok = ntok; p.ntok_pad = ntok; p.heads = heads; p.dh = dh; p.C = C;
   return launch_st_mid(p, (hipStream_t)stream);
 }
+int sdmi_k_st_mid_ctx(const void* a_f16, const void* wo_f16, const float* bo, float* t, const float* ln_gamma, float ln_eps, const void* wq_f16,
+                      const float* lnf_cs, const float* lnf_d, const void* ctx_k, const void* ctx_vt, int nkv, int nkv_pad, float scale, void* ao_out,
+                      int B, int ntok, int heads, int dh, int C, void* stream) {
+  StHeadParams p;
+  p.a16 = (const f16*)a_f16; p.w_in = (const f16*)wo_f16; p.b_in = bo; p.t = t; p.ln_gamma = ln_gamma; p.ln_eps = ln_eps;
+  p.wqkv = (const f16*)wq_f16; p.lnf_cs = lnf_cs; p.lnf_d = lnf_d;
+  p.ctx_k = (const f16*)ctx_k; p.ctx_vt = (const f16*)ctx_vt; p.ctx_nkv = nkv; p.ctx_nkv_pad = nkv_pad; p.ctx_scale = scale; p.ao_out = (f16*)ao_out;
+  SDMI_CHECK(ctx_k && ctx_vt && ao_out, "st_mid_ctx: null argument");
+  p.M = B * ntok; p.B = B; p.ntok = ntok; p.ntok_pad = ntok; p.heads = heads; p.dh = dh; p.C = C;
+  return launch_st_mid(p, (hipStream_t)stream);
+}
 int sdmi_k_ln_fold_prep(const void* w_f16, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias,
                         float* cs, float* d, void* stream) {
   return launch_ln_fold_prep((const f16*)w_f16, N, K, ldw, gamma, beta, bias, cs, d, (hipStream_t)stream);

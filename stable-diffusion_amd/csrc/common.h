@@ -326,6 +326,9 @@ struct StHeadParams {
   f16* q = nullptr; f16* k = nullptr;  // [B * heads][ntok][dh]
   f16* vt = nullptr;               // [B * heads][dh][ntok_pad]
   int M = 0, B = 0, ntok = 0, ntok_pad = 0, heads = 0, dh = 0, C = 0;
+  // (launch_st_mid, optional) the cross-attention behind to_q inside the launch: cached context K [B * heads][nkv][dh] and V^T
+  // [B * heads][dh][nkv_pad] (TBlock::ck / cvt), softmax scale, the attention output rows ao_out [M][C] fp16; `q` is then not written
+  const f16* ctx_k = nullptr; const f16* ctx_vt = nullptr; int ctx_nkv = 0, ctx_nkv_pad = 0; float ctx_scale = 0.f; f16* ao_out = nullptr;
 #ifdef SDMI_RC_TIMING
   long long* dbg = nullptr;
 #endif

@@ -544,6 +544,18 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD + (PF ? 64 : 0)) ff_tail_ker
 //     attention.py:212 (x = attn1(norm1(x)) + x: CrossAttention.to_out, :191-192), :213 + :170 (attn2.to_q over norm2(x))
 // -- the out-projection of the self-attention (operand strip by LDS-DMA, residual = the token stream, updated in place) and the query
 // projection of the cross-attention (10 + 10 units) instead of two GEMM launches.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+#if defined(__HIP_DEVICE_COMPILE__)
+// max over the two 32-lane halves of the wave, in every lane (attn.hip: v_permlane32_swap, a VALU instruction)
+__device__ __forceinline__ void rc_swap_halves(float& a, float& b) {      // a.hi <-> b.lo
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float rc_max_across_halves(float x) {
+  float a = x, b = x;
+  rc_swap_halves(a, b);
+  return fmaxf(a, b);
+}
+#endif
 constexpr int SH_NU = 2 * FT_BLK + 3 * FT_BLK;                           // head: 50 units; middle: the first 20
 struct ShUnitTab { int soff[2][SH_NU]; int sel[2][SH_NU]; };
 constexpr ShUnitTab sh_make_tab() {
@@ -564,7 +576,15 @@ constexpr ShUnitTab sh_make_tab() {
 }
 __device__ const ShUnitTab kShTab = sh_make_tab();
 
-template <int C, int NLD, int KIND, int NS = RC_NS, bool PF = false>
+//
+// CTX (KIND 1 only): the CROSS-ATTENTION behind to_q inside the same launch (attention.py:213, 170-193 with the cached context K / V^T):
+// q stays in LDS (fp16, the bits the scatter would have stored), compute wave w runs heads w and w + 5 for the strip's 32 query rows --
+// attn_dma_kernel's loop on the same values in the same order (64-key tiles in the permuted row order, S^T = K Q^T, running max with the
+// wave-wide rescale test, packed-fma exp2, P^T fed back from the accumulator registers, the softmax denominator as row D of O^T through a
+// ones row, IEEE division at the end), with the K / V^T fragments read straight from memory (16-byte buffer loads through the same
+// descriptors: the same bytes the LDS-DMA image would hold, zeros out of range) -- the attention output rows are the same bits as the
+// attention launch's.  d = 40 (C = 320, 8 heads), at most 128 context keys.
+template <int C, int NLD, int KIND, int NS = RC_NS, bool PF = false, bool CTX = false>
 __global__ void __launch_bounds__(RC_NTC + 64 * NLD + (PF ? 64 : 0)) st_head_kernel(const StHeadParams rp) {
 #if defined(__HIP_DEVICE_COMPILE__)
   static_assert(C == FT_C, "unit geometry: five waves x 64 columns = C");
@@ -896,6 +916,153 @@ __global__ void __launch_bounds__(RC_NTC + 64 * NLD + (PF ? 64 : 0)) st_head_ker
   zero2(acc);
   block(acc, OFF_XN, ln_table);                         // q
   SH_STAMP();
+  if constexpr (KIND == 1 && CTX) {
+    static_assert(C == 320, "head dim 40: eight heads of five 16-byte chunks");
+    constexpr int D = 40, DKS = 3, DVT = 2, KVT = 64;
+    const float sc = rp.ctx_scale * 1.4426950408889634f;
+    const int nt = (rp.ctx_nkv + KVT - 1) / KVT;                        // 1 or 2 (the launcher checked nkv <= 128)
+    const int nheads = (rp.heads - wave + RC_NWC - 1) / RC_NWC;         // this wave's heads: wave, wave + 5
+    const int nsteps = nheads * nt;                                     // (head, tile) steps: at most 4
+    // the fragments of step i = (head wave + 5 (i / nt), tile i % nt): K rows in the permuted order (bits 2 and 3 of the row swapped),
+    // V^T rows d (row D = ones, beyond: zeros).  Two register sets: step i + 2 is requested while step i + 1 is computed.
+    auto load_frags = [&](int i, u32x4 (&kf)[2][DKS], u32x4 (&vf)[2][2][DVT]) {
+      const int head = wave + RC_NWC * (nt == 2 ? (i >> 1) : i), t = nt == 2 ? (i & 1) : 0;
+      const int bh = bsample * rp.heads + head;
+      const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc((void*)(rp.ctx_k + (size_t)bh * rp.ctx_nkv * D), 0, rp.ctx_nkv * D * 2, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc((void*)(rp.ctx_vt + (size_t)bh * D * rp.ctx_nkv_pad), 0, D * rp.ctx_nkv_pad * 2, 0x00020000);
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb) {
+        const int row = kvb * 32 + l31;
+        const int key = t * KVT + ((row & ~12) | ((row & 4) << 1) | ((row & 8) >> 1));
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks) kf[kvb][ks] = __builtin_amdgcn_raw_buffer_load_b128(rsrc_k, key * (D * 2) + (ks * 2 + lg) * 16, 0, 0);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int dt = 0; dt < DVT; ++dt) {
+            const int d = dt * 32 + l31;
+            const unsigned one2 = d == D ? 0x3C003C00u : 0u;
+            u32x4 v = {one2, one2, one2, one2};
+            if (d < D) v = __builtin_amdgcn_raw_buffer_load_b128(rsrc_v, d * (rp.ctx_nkv_pad * 2) + t * (KVT * 2) + (4 * kvb + 2 * s2 + lg) * 16, 0, 0);
+            vf[kvb][s2][dt] = v;
+          }
+      }
+    };
+    f16x8 qf[DKS];
+    f32x16 o[DVT];
+    float m_run = -1e30f;
+    auto step = [&](int i, const u32x4 (&kf)[2][DKS], const u32x4 (&vf)[2][2][DVT]) {
+      const int head = wave + RC_NWC * (nt == 2 ? (i >> 1) : i), t = nt == 2 ? (i & 1) : 0;
+      if (t == 0) {
+        // Q^T fragments: lane (q = l31, g = lg) holds q[q][40 head + 16 ks + 8 g .. + 8]; zero beyond D
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks) {
+          const int dcol = ks * 16 + lg * 8;
+          f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+          if (dcol < D) v = *(const f16x8*)(smem + OFF_XN + strip_off(l31, head * D + dcol));
+          qf[ks] = v;
+        }
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+        m_run = -1e30f;
+      }
+      // ---- S^T = K Q^T (two 32-key blocks) ----
+      f32x16 sa[2];
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sa[kvb][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < DKS; ++ks)
+          sa[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kf[kvb][ks]), qf[ks], sa[kvb], 0, 0, 0);
+      }
+      const int kv0 = t * KVT;
+      if (kv0 + KVT > rp.ctx_nkv) {
+#pragma unroll
+        for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int kv = kv0 + kvb * 32 + (r & 3) + 4 * ((r >> 2) & 1) + 8 * lg + 16 * (r >> 3);
+            if (kv >= rp.ctx_nkv) sa[kvb][r] = -1e30f;
+          }
+      }
+      float mx = -1e30f;
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sa[kvb][r]);
+      mx = rc_max_across_halves(mx);
+      const float m_new = fmaxf(m_run, mx * sc);
+      if (__any(m_new > m_run)) {
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+      }
+      const f32x2 sc2 = {sc, sc}, nm2 = {-m_run, -m_run};
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const f32x2 sv = {sa[kvb][r], sa[kvb][r + 1]};
+          const f32x2 e = __builtin_elementwise_fma(sv, sc2, nm2);
+          sa[kvb][r] = __builtin_amdgcn_exp2f(e[0]);
+          sa[kvb][r + 1] = __builtin_amdgcn_exp2f(e[1]);
+        }
+      // ---- O^T += V^T P^T ----
+#pragma unroll
+      for (int kvb = 0; kvb < 2; ++kvb)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          f16x8 pf;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) pf[e] = (f16)sa[kvb][8 * s2 + e];
+#pragma unroll
+          for (int dt = 0; dt < DVT; ++dt)
+            o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, vf[kvb][s2][dt]), pf, o[dt], 0, 0, 0);
+        }
+      if (t == nt - 1) {
+        // the denominator: row D of O^T = tile D / 32, local row D % 32 = 8: register (8 & 3) + 4 (8 >> 3) = 4 of lane half (8 >> 2) & 1 = 0
+        float la = o[D / 32][4], lb = la;
+        rc_swap_halves(la, lb);
+        const float inv = 1.0f / la;
+        f16* orow = rp.ao_out + (size_t)(m0 + l31) * C + (size_t)head * D;
+#pragma unroll
+        for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+          for (int r4 = 0; r4 < 4; ++r4) {
+            const int dd = dt * 32 + 8 * r4 + 4 * lg;
+            if (dd < D) {
+              const f16x4 v = {(f16)(o[dt][r4 * 4 + 0] * inv), (f16)(o[dt][r4 * 4 + 1] * inv), (f16)(o[dt][r4 * 4 + 2] * inv), (f16)(o[dt][r4 * 4 + 3] * inv)};
+              SDMI_ST(f16x4, orow + dd, v);
+            }
+          }
+      }
+    };
+    u32x4 kfa[2][DKS], vfa[2][2][DVT], kfb[2][DKS], vfb[2][2][DVT];
+    if (nsteps > 0) load_frags(0, kfa, vfa);          // (K / V^T do not depend on q: requested in front of the fold and the q strip)
+    if (nsteps > 1) load_frags(1, kfb, vfb);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (pairs with the loaders' last barrier: they are gone after it)
+    fold(acc, fcs[0], fdn[0]);
+    // q -> fp16 strip in LDS (over the dead out-projection operand strip), in strip_off's layout: the values rows_out would have stored
+    slab_put<2, LSTR>(wl, acc, l31, lg);
+#pragma unroll
+    for (int qq = 0; qq < 8; ++qq) {
+      const int row = qq * 4 + rl;
+      const f32x4 v = *(const f32x4*)(wl + row * LSTR + c4);
+      *(f16x4*)(smem + OFF_XN + strip_off(row, nw + c4)) = f16x4{(f16)v[0], (f16)v[1], (f16)v[2], (f16)v[3]};
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // a head's 40 columns come from two waves
+    if (nsteps > 0) { step(0, kfa, vfa); if (nsteps > 2) load_frags(2, kfa, vfa); }
+    if (nsteps > 1) { step(1, kfb, vfb); if (nsteps > 3) load_frags(3, kfb, vfb); }
+    if (nsteps > 2) step(2, kfa, vfa);
+    if (nsteps > 3) step(3, kfb, vfb);
+    return;
+  }
   if constexpr (KIND == 1) {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");    // (pairs with the loaders' last barrier)
     fold(acc, fcs[0], fdn[0]);
@@ -1041,17 +1208,23 @@ int launch_st_head(const StHeadParams& p, hipStream_t stream) {
 // ln_gamma = norm2 weight, wqkv = Wq [C][C], lnf_cs / lnf_d [C], q)
 int launch_st_mid(const StHeadParams& p, hipStream_t stream) {
   SDMI_CHECK(st_head_supported(p.C, p.M, p.ntok, p.ntok_pad > 0 ? p.ntok_pad : p.ntok, p.heads, p.dh), "st_mid: C = 320, rows (per sample) multiples of 32, heads * dh = C, dh % 4 = 0");
-  SDMI_CHECK(p.a16 && p.w_in && p.b_in && p.t && p.ln_gamma && p.wqkv && p.lnf_cs && p.lnf_d && p.q, "st_mid: null operand");
+  const bool ctx = p.ctx_k != nullptr;
+  SDMI_CHECK(p.a16 && p.w_in && p.b_in && p.t && p.ln_gamma && p.wqkv && p.lnf_cs && p.lnf_d && (ctx || p.q), "st_mid: null operand");
+  SDMI_CHECK(!ctx || (p.ctx_vt && p.ao_out && p.dh == 40 && p.ctx_nkv >= 1 && p.ctx_nkv <= 128 && p.ctx_nkv_pad % 8 == 0 && p.ctx_nkv_pad >= p.ctx_nkv),
+             "st_mid with the cross-attention inside: head dim 40, 1 .. 128 context keys, V^T rows padded to a multiple of 8");
   SDMI_CHECK(p.B * p.ntok == p.M, "st_mid: M = B * ntok");
   const double M = p.M, C = p.C;
-  ProfScope ps("st_mid_32x320w5", 2.0 * M * (2.0 * C * C), M * C * (2.0 + 4.0 + 4.0 + 2.0) + 2.0 * C * C * 2.0, stream);
+  // (with the cross-attention inside: + 4 B h N Nkv d flops of the attention product)
+  ProfScope ps(ctx ? "st_mid_ctx_32x320w5" : "st_mid_32x320w5", 2.0 * M * (2.0 * C * C) + (ctx ? 4.0 * M * p.ctx_nkv * C : 0.0),
+               M * C * (2.0 + 4.0 + 4.0 + 2.0) + 2.0 * C * C * 2.0, stream);
   StHeadParams q = p;
   const dim3 grid(p.M / RC_ROWS);
   const int nld = env_int("SDMI_FF_TAIL_LD", RC_NLD_DEFAULT);
 #ifdef SDMI_RC_TIMING
   q.dbg = g_sh_dbg;
 #endif
-  if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  if (ctx) hipLaunchKernelGGL((st_head_kernel<320, 2, 1, RC_NS, true, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+  else if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
   else if (env_int("SDMI_CHAIN_PF", 1)) hipLaunchKernelGGL((st_head_kernel<320, 2, 1, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
   else hipLaunchKernelGGL((st_head_kernel<320, 2, 1>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());

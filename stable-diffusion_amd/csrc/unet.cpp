@@ -463,6 +463,7 @@ struct Fwd : FwdBase {
   bool st_head_on = false;      // ... and SpatialTransformer heads (UNet::st_head_; SDMI_ST_HEAD, read per call)
   bool st_mid_on = false;       // ... and the out-projection of attn1 with attn2's to_q (SDMI_ST_MID)
   bool st_tail_on = false;      // ... and the out-projection of attn2 in front of the tail's chain launch (SDMI_ST_TAIL)
+  bool st_mid_ctx_on = false;   // ... and the cross-attention inside the st_mid launch (SDMI_ST_MID_CTX)
   bool gn_conv_on = false;      // ResBlock GroupNorm + SiLU + conv3x3 as one launch where a workgroup can own all output columns (gnconv.hip; SDMI_GN_CONV)
   // cross-attention with the to_q projection inside the kernel (attn_ctx.hip), SDMI_ATTN_CTX_FUSED=1.  Default off: same-box A/B,
   // round 3 (profiles/experiments_r03.txt): 5.98 vs 5.88 ms per UNet call -- -3.8 us per launch at d = 40, +1.4 at d = 80, +13 at d = 160
@@ -689,12 +690,17 @@ struct Fwd : FwdBase {
       attention(q, k, vt, ao, L, N, N, Np, scale);
       // attn1's out-projection (+ x) and attn2's to_q over norm2 as one row-strip chain launch (rowchain.hip, st_head_kernel KIND 1)
       const bool ctx_fused_here = fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx) && !(fold_ln && C > 640);
+      bool chain_ctx = false;
       const bool chain_mid = st_mid_on && fold_ln && !ctx_fused_here && T.lnf[2] != nullptr && st_head_supported(C, M, N, Np, L.heads, L.dh);
       if (chain_mid) {
         StHeadParams h;
         h.a16 = ao; h.w_in = T.wo1; h.b_in = T.bo1; h.t = t; h.ln_gamma = T.ln[2]; h.ln_eps = 1e-5f;
         h.wqkv = T.wq2; h.lnf_cs = T.lnf[2]; h.lnf_d = T.lnf[3]; h.q = q;
         h.M = M; h.B = B; h.ntok = N; h.ntok_pad = Np; h.heads = L.heads; h.dh = L.dh; h.C = C;
+        if (ctx16) context_kv(L, d);
+        // ... and the cross-attention itself inside that launch (st_head_kernel CTX: q never leaves the CU)
+        chain_ctx = st_mid_ctx_on && L.dh == 40 && Lctx <= 128;
+        if (chain_ctx) { h.ctx_k = T.ck; h.ctx_vt = T.cvt; h.ctx_nkv = Lctx; h.ctx_nkv_pad = Lp; h.ctx_scale = scale; h.ao_out = ao; }
         if (!dry && !rc) ok(launch_st_mid(h, s));
       } else {
         IGemmParams p = dense(ao, M, C, T.wo1, C, N);
@@ -703,9 +709,9 @@ struct Fwd : FwdBase {
         gemm(p);
       }
       // x = attn2(norm2(x), context) + x                           attention.py:213
-      if (ctx16) context_kv(L, d);
+      if (ctx16 && !chain_mid) context_kv(L, d);
       if (chain_mid) {
-        attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);       // (q = to_q(norm2(t)) came out of the chain launch)
+        if (!chain_ctx) attention(q, T.ck, T.cvt, ao, L, N, Lctx, Lp, scale);       // (q = to_q(norm2(t)) came out of the chain launch)
       } else if (fuse_ctx_q && L.dh <= fuse_ctx_maxd && attention_ctx_supported(L.dh, C, Lctx) && !(fold_ln && C > 640)) {
         // to_q inside the attention kernel (attn_ctx.hip): one launch for q = norm2(x) Wq^T and softmax(q K^T) V
         AttnCtxParams a;
@@ -925,6 +931,8 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     f.st_mid_on = e_sm ? atoi(e_sm) != 0 : st_head_;
     const char* e_st = getenv("SDMI_ST_TAIL");
     f.st_tail_on = e_st ? atoi(e_st) != 0 : ff_tail_;
+    const char* e_mc = getenv("SDMI_ST_MID_CTX");
+    f.st_mid_ctx_on = e_mc ? atoi(e_mc) != 0 : st_head_;
     const char* e_gc = getenv("SDMI_GN_CONV");
     f.gn_conv_on = e_gc ? atoi(e_gc) != 0 : false;       // (opt-in: bit-identical, 36 us against 41 us with hot operands, +4 us per launch inside a UNet call -- profiles/gn_conv3_r05.txt)
 #ifdef SDMI_EXPERIMENTS      // (kernels of the experiments build: attn_ctx.hip, gemm_split16_gn_kernel)

@@ -174,6 +174,13 @@ def st_mid(a16, wo16, bo, t, ln_gamma, ln_eps, wq16, cs, dn, q, B, ntok, heads, 
                                          wq16.data_ptr(), cs.data_ptr(), dn.data_ptr(), q.data_ptr(), B, ntok, heads, dh, a16.shape[1], _s()))
 
 
+def st_mid_ctx(a16, wo16, bo, t, ln_gamma, ln_eps, wq16, cs, dn, ck, cvt, nkv, scale, ao_out, B, ntok, heads, dh):
+    """st_mid with the cross-attention behind to_q inside the launch (sdmi_k_st_mid_ctx): ck [B * heads, nkv, dh], cvt [B * heads, dh, nkv_pad]"""
+    _lib.check(_lib.load().sdmi_k_st_mid_ctx(a16.data_ptr(), wo16.data_ptr(), bo.data_ptr(), t.data_ptr(), ln_gamma.data_ptr(), float(ln_eps),
+                                             wq16.data_ptr(), cs.data_ptr(), dn.data_ptr(), ck.data_ptr(), cvt.data_ptr(), nkv, cvt.shape[2],
+                                             float(scale), ao_out.data_ptr(), B, ntok, heads, dh, a16.shape[1], _s()))
+
+
 _CNT = {}
 
 

@@ -21,7 +21,7 @@ def test_library_exports_every_declared_symbol():
     nm = subprocess.run(['nm', '-D', '--defined-only', _lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r' T (sdmi_[a-z0-9_]+)', nm))
     assert declared <= exported, declared - exported
-    assert lib.sdmi_abi_version() == 15
+    assert lib.sdmi_abi_version() == 16
     for name in declared:
         assert hasattr(lib, name)
 

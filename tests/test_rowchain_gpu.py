@@ -285,3 +285,67 @@ def test_st_mid_is_bit_identical_to_the_two_launches(B, ntok):
     assert K.report(f'st_mid q B{B} n{ntok}', q.float(), q_ref, 2e-2) < 2e-2
     print(f'[st_mid vs launches] t / q equal: {torch.equal(t, t0)} {torch.equal(q, q0)}', flush=True)
     assert torch.equal(t, t0) and torch.equal(q, q0)
+
+
+@pytest.mark.parametrize('B,ntok,nkv', [(2, 4096, 77), (1, 64, 77), (3, 128, 64), (2, 9216, 77), (2, 256, 128), (1, 32, 5)])
+def test_st_mid_with_the_cross_attention_inside_is_bit_identical_to_the_launches(B, ntok, nkv):
+    """out-projection of attn1 -> to_q over norm2 -> softmax(q K^T d^-1/2) V over the cached context (attention.py:212-213, 170-193) as ONE launch
+    (st_head_kernel CTX) against the st_mid launch + the attention launch: the token stream and the attention output rows bit for bit, and
+    the attention output against fp32 torch."""
+    g = _g(1977 + ntok + nkv)
+    C_, heads = 320, 8
+    dh, M = C_ // heads, B * ntok
+    nkp = (nkv + 7) // 8 * 8
+    d = lambda t: t.to(DEV)
+    ao = (torch.randn(M, C_, generator=g) * 0.7).half()
+    wo = (torch.randn(C_, C_, generator=g) / math.sqrt(C_)).half()
+    bo = torch.randn(C_, generator=g) * 0.1
+    t_prev = torch.randn(M, C_, generator=g) * 1.5 + 0.3
+    ln_g = 1 + 0.2 * torch.randn(C_, generator=g); ln_b = 0.1 * torch.randn(C_, generator=g)
+    wq = (torch.randn(C_, C_, generator=g) / math.sqrt(C_)).half()
+    ck = (torch.randn(B * heads, nkv, dh, generator=g) * 1.2).half()
+    cv = (torch.randn(B * heads, nkv, dh, generator=g)).half()
+    cvt = torch.zeros(B * heads, dh, nkp, dtype=torch.float16); cvt[:, :, :nkv] = cv.transpose(1, 2)
+    scale = dh ** -0.5
+    cs, dn = K.ln_fold_prep(d(wq), C_, d(ln_g), d(ln_b))
+    # the launches: st_mid, then the attention kernel
+    t0 = d(t_prev).clone()
+    q0 = torch.full((B * heads, ntok, dh), float('nan'), dtype=torch.float16, device=DEV)
+    K.st_mid(d(ao), d(wo), d(bo), t0, d(ln_g), 1e-5, d(wq), cs, dn, q0, B, ntok, heads, dh)
+    a0 = K.attention(q0, d(ck), d(cvt), heads, nkv, scale).view(M, C_)
+    # one launch
+    t = d(t_prev).clone()
+    a1 = torch.full((M, C_), float('nan'), dtype=torch.float16, device=DEV)
+    K.st_mid_ctx(d(ao), d(wo), d(bo), t, d(ln_g), 1e-5, d(wq), cs, dn, d(ck), d(cvt), nkv, scale, a1, B, ntok, heads, dh)
+    torch.cuda.synchronize()
+    qf = q0.float().cpu()
+    ref = torch.softmax(qf @ ck.float().transpose(1, 2) * scale, dim=-1) @ cv.float()
+    ref = ref.view(B, heads, ntok, dh).permute(0, 2, 1, 3).reshape(M, C_)
+    assert K.report(f'st_mid_ctx attention B{B} n{ntok} nkv{nkv}', a1.float(), ref, 3e-3) < 3e-3
+    eq = [torch.equal(t, t0), torch.equal(a1, a0)]
+    print(f'[st_mid_ctx vs launches] t / attention output equal: {eq}; max diff {float((a1.float() - a0.float()).abs().max()):.3e}', flush=True)
+    assert all(eq), eq
+
+
+def test_st_mid_ctx_repeats_bit_identically_next_to_other_work():
+    g = _g(31)
+    B, ntok, nkv, C_, heads = 2, 4096, 77, 320, 8
+    dh, M = 40, B * ntok
+    d = lambda t: t.to(DEV)
+    ao = d((torch.randn(M, C_, generator=g) * 0.7).half()); wo = d((torch.randn(C_, C_, generator=g) / math.sqrt(C_)).half())
+    bo = d(torch.randn(C_, generator=g) * 0.1); t_prev = d(torch.randn(M, C_, generator=g) * 1.5 + 0.3)
+    ln_g = d(1 + 0.2 * torch.randn(C_, generator=g)); ln_b = d(0.1 * torch.randn(C_, generator=g))
+    wq = d((torch.randn(C_, C_, generator=g) / math.sqrt(C_)).half())
+    ck = d((torch.randn(B * heads, nkv, dh, generator=g) * 1.2).half())
+    cvt = torch.zeros(B * heads, dh, 80, dtype=torch.float16); cvt[:, :, :nkv] = torch.randn(B * heads, dh, nkv, generator=g).half(); cvt = d(cvt)
+    cs, dn = K.ln_fold_prep(wq, C_, ln_g, ln_b)
+    junk = torch.empty(96 << 20, device=DEV)
+    first = None
+    for i in range(20):
+        if i % 2:
+            junk.fill_(float(i))
+        t = t_prev.clone(); a1 = torch.full((M, C_), float('nan'), dtype=torch.float16, device=DEV)
+        K.st_mid_ctx(ao, wo, bo, t, ln_g, 1e-5, wq, cs, dn, ck, cvt, nkv, dh ** -0.5, a1, B, ntok, heads, dh)
+        if first is None:
+            first = (t, a1)
+        assert torch.equal(t, first[0]) and torch.equal(a1, first[1]), i
