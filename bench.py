@@ -147,8 +147,10 @@ def unet_latency_ms(unet, device, H=64, W=64, iters=10):
     t0 = time.perf_counter()
     for _ in range(iters):
         unet(x, t, context=ctx)
+    t_host = time.perf_counter() - t0          # the host is done ENQUEUEING here; if this is the whole time, the call is host-bound
     torch.cuda.synchronize()
     unet.unpin_context()
+    unet_latency_ms.host_enqueue_ms = t_host / iters * 1e3
     return (time.perf_counter() - t0) / iters * 1e3
 
 
@@ -211,7 +213,75 @@ def box_probe(device):
         sclk = None
     torch.cuda.synchronize()
     out['sclk_mhz'] = sclk
-    out['note'] = 'mid boxes of the pool: empty_launch ~2.5 us, attn_d160_ctx ~11-13 us; slow boxes: ~1.7-2.2x on attn_d160_ctx (profiles/bench_r04_*slow_box.json)'
+    # Round 5: the three probes above run with hot caches and do NOT separate the pool's box classes any more (three boxes at 5.2 / 6.5 / 6.6 ms per
+    # UNet call showed the same 9.4 us / 510 TFLOP/s / 3 us).  Two HBM-side probes (they turned out not to separate the classes either) and a
+    # kernel-switching probe (which does: profiles/bench_r05_boxes.txt):
+    #   hbm_copy_gbs        a 1 GiB device-to-device copy (read + write), GB/s;
+    #   cold_conv_us        the weight-streaming class: the 3 x 3 conv 1280 -> 1280 of the 8 x 8 level (M = 128, 29.5 MB of weights, split-K + reduce)
+    #                       over 12 distinct weight buffers round-robin (354 MB: nothing survives in the 256 MB Infinity Cache);
+    #   cold_conv_hot_us    the same launch on one buffer (weights cache-resident), for the ratio
+    try:
+        big_a = torch.empty(1 << 28, dtype=torch.float32, device=device); big_b = torch.empty_like(big_a)
+        big_a.fill_(1.0)
+        us = timed(lambda: big_b.copy_(big_a), 5, 2)
+        out['hbm_copy_gbs'] = round(2.0 * big_a.numel() * 4 / us * 1e-3, 0)
+        del big_a, big_b
+        Bc, Hc, Cc = 2, 8, 1280
+        a2 = (torch.randn(Bc * Hc * Hc, Cc, generator=g) * 0.5).half().to(device)
+        w0 = (torch.randn(Cc, 9 * Cc, generator=g) * 0.01).half().to(device)
+        ws = [w0] + [w0.clone() for _ in range(11)]
+        o2 = torch.empty(Bc * Hc * Hc, Cc, device=device)
+        wsp = torch.empty(16 * (Bc * Hc * Hc + 255) * (Cc + 255), dtype=torch.float32, device=device)
+        d2 = _lib.IGemmDesc()
+        d2.a0 = a2.data_ptr(); d2.c0 = Cc; d2.lda0 = Cc
+        d2.B, d2.Hin, d2.Win, d2.Hout, d2.Wout, d2.ksize, d2.stride = Bc, Hc, Hc, Hc, Hc, 3, 1
+        d2.N = Cc; d2.out_f32 = o2.data_ptr(); d2.ldo = Cc; d2.splitk = 0; d2.tile = -1; d2.dma = -1
+        d2.splitk_ws = wsp.data_ptr(); d2.splitk_ws_floats = wsp.numel()
+        state = {'i': 0}
+
+        def cold():
+            d2.w = ws[state['i'] % len(ws)].data_ptr(); state['i'] += 1
+            _lib.check(lib.sdmi_k_igemm(ctypes.byref(d2), s_))
+
+        def hot():
+            d2.w = ws[0].data_ptr()
+            _lib.check(lib.sdmi_k_igemm(ctypes.byref(d2), s_))
+        out['cold_conv_us'] = round(timed(cold, 120, 24), 2)
+        out['cold_conv_hot_us'] = round(timed(hot, 120, 24), 2)
+        # ... and a CODE-side probe: the same small GEMM (M 512, N 1280, K 1280, operands cache-resident) through 18 different tile instantiations
+        # round-robin (every launch starts with another kernel's code: instruction-cache-cold starts, as inside a UNet call, where ~40 kernels
+        # alternate) against one instantiation repeated
+        a3 = (torch.randn(512, 1280, generator=g) * 0.5).half().to(device)
+        w3 = (torch.randn(1280, 1280, generator=g) * 0.02).half().to(device)
+        o3 = torch.empty(512, 1280, device=device)
+        d3 = _lib.IGemmDesc()
+        d3.a0 = a3.data_ptr(); d3.c0 = 1280; d3.lda0 = 1280
+        d3.B, d3.Hin, d3.Win, d3.Hout, d3.Wout, d3.ksize, d3.stride = 1, 512, 1, 512, 1, 1, 1
+        d3.w = w3.data_ptr(); d3.N = 1280; d3.out_f32 = o3.data_ptr(); d3.ldo = 1280; d3.splitk = 1; d3.dma = -1
+        tiles = [0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 18, 19, 20, 21]
+        st3 = {'i': 0}
+
+        def mixed():
+            d3.tile = tiles[st3['i'] % len(tiles)]; st3['i'] += 1
+            _lib.check(lib.sdmi_k_igemm(ctypes.byref(d3), s_))
+
+        def same():
+            d3.tile = 5
+            _lib.check(lib.sdmi_k_igemm(ctypes.byref(d3), s_))
+        out['mixed_kernels_us'] = round(timed(mixed, 180, 36), 2)
+        out['same_kernel_us'] = round(timed(same, 180, 36), 2)
+        # the same 18 instantiations, each repeated 10 x in a row (hot code): the average that mixed_kernels_us is to be compared with
+        tot = 0.0
+        for tl in tiles:
+            d3.tile = tl
+            tot += timed(lambda: _lib.check(lib.sdmi_k_igemm(ctypes.byref(d3), s_)), 10, 4) * 10
+        out['mixed_set_hot_us'] = round(tot / (10 * len(tiles)), 2)
+    except Exception as e:      # noqa: BLE001  (a probe must never fail the bench)
+        out['hbm_probe_error'] = f'{type(e).__name__}: {e}'[:200]
+    out['note'] = ('round 5, 14 boxes (profiles/bench_r05_boxes.txt): the hot probes (empty_launch / attn_d160_ctx / conv_tflops) and the HBM-side ones '
+                   '(hbm_copy_gbs / cold_conv_us) read the same on the fast (5.2 - 5.4 ms per UNet call) and slow (6.4 - 6.6 ms) boxes of the pool; '
+                   'mixed_kernels_us separates them (fast ~14.5 us, slow ~16.1 us; mixed_set_hot_us = the same kernels without switching), and so does '
+                   'unet_host_enqueue_ms_per_call (fast ~3.5 ms, slow ~4.4 ms)')
     return out
 
 
@@ -488,6 +558,7 @@ def main():
             out['box_probe'] = box_probe(device)
             ms = unet_latency_ms(unet, device, H=LAT, W=LAT)
             out['unet_ms_per_call'] = ms
+            out['unet_host_enqueue_ms_per_call'] = round(getattr(unet_latency_ms, 'host_enqueue_ms', float('nan')), 3)   # host time to enqueue one call
             out['unet_calls_per_image'] = wl['calls']
             out['unet_tflops'] = UNET_GFLOP[LAT] / ms
             out['vae_decode_ms'] = vae_latency_ms(vae, device, H=LAT)
