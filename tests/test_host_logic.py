@@ -556,3 +556,30 @@ def test_row_to_sample_magic_division_model():
                 assert fdiv(m, mg, 48) == m // hw, (hw, B, m)
     hw, m = 768 * 768, 4 * 768 * 768 - 1
     assert fdiv(m, magic(hw, 40), 40) == 4 and m // hw == 3       # the bug the 2^48 form fixes
+
+
+def test_prefetch_wave_covers_every_line_of_a_unit_exactly_once():
+    """CPU model of the XCD-cooperative prefetch wave of the row-strip chain kernels (csrc/rowchain.hip rc_pf_row, csrc/gnconv.hip): the
+    workgroups of an XCD (slot = blockIdx / 8 of gridDim / 8) share the 160 weight rows of a 20 KB unit -- lane -> line slot + (lane / 4) * nslots,
+    32-byte sector lane % 4.  For every grid the chain kernels are launched with (M / 32 workgroups, M = B * ntok), each of the 160 lines x 4
+    sectors is touched exactly once per XCD, and the row offset is the loaders' (64 w + [0, 32) of compute wave w)."""
+    for M in (64 * 32 // 2, 8192, 4096, 18432, 16384, 2048, 256 * 32):
+        ntiles = M // 32
+        if ntiles % 8:
+            continue                                   # (no prefetch: the kernel's slot is out of range)
+        nslots = max(ntiles // 8, 10)
+        seen = {}
+        for slot in range(ntiles // 8):
+            for lane in range(64):
+                idx = slot + (lane >> 2) * nslots
+                if slot < nslots and idx < 160:
+                    row = 64 * (idx >> 5) + (idx & 31)
+                    key = (row, lane & 3)
+                    assert key not in seen, (M, slot, lane)
+                    seen[key] = 1
+        rows = sorted({r for r, _ in seen})
+        want = sorted(64 * w + r for w in range(5) for r in range(32))
+        if ntiles // 8 >= 10:                          # enough workgroups per XCD: full coverage
+            assert rows == want and len(seen) == 160 * 4, (M, len(seen))
+        else:                                          # tiny grids: a prefix of the slots exists; whatever is touched is a valid line
+            assert set(rows) <= set(want)
