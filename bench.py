@@ -289,7 +289,7 @@ def offline_traffic(kernel_class):
     """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC pass (profiles/traffic_rNN.json, the newest);
     PMC counters cannot be collected inside this process, so `roofline.traffic` is read from that committed pass."""
     try:
-        path = next(p_ for p_ in (os.path.join(ROOT, 'profiles', f'traffic_r0{r}.json') for r in (5, 4, 3, 2)) if os.path.exists(p_))
+        path = next(p_ for p_ in (os.path.join(ROOT, 'profiles', f'traffic_r0{r}.json') for r in (6, 5, 4, 3, 2)) if os.path.exists(p_))
         d = json.load(open(path))
         k = d['kernels'].get(kernel_class)
         if k:
@@ -310,7 +310,7 @@ def traffic_pass(out_json=None, keep_dir=None, also=None):
     import sqlite3
     import subprocess
     import tempfile
-    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r05.json')
+    out_json = out_json or os.path.join(ROOT, 'profiles', 'traffic_r06.json')
     work = keep_dir or tempfile.mkdtemp(prefix='sdmi_traffic_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
     per = {}
@@ -379,23 +379,30 @@ def usable_cores():
 
 
 def reference_unet():
-    """The real reference UNetModel (ldm/modules/diffusionmodules/openaimodel.py) when its sources are visible -- the build
-    container has them under /root/reference (or $SD_REFERENCE); a GPU box does not.  Returns a callable
-    (x, t, context) -> eps with the oracle's synthetic SD-v1 weights loaded strict=True, or None."""
+    """The real reference UNetModel (ldm/modules/diffusionmodules/openaimodel.py): from its sources when they are visible (the
+    build container has them under /root/reference or $SD_REFERENCE), else from the bytecode bundle oracle/build_ref_bundle.py
+    compiled from them (oracle/_ref/refbundle: git-ignored, travels to the GPU box with the snapshot like the built .so --
+    the same bundle tests/test_reference_script_gpu.py runs there).  Returns (callable (x, t, context) -> eps with the oracle's
+    synthetic SD-v1 weights loaded strict=True, where it came from) or (None, None)."""
     ref = os.environ.get('SD_REFERENCE', '/root/reference')
-    if not os.path.isdir(os.path.join(ref, 'ldm')):
-        return None
+    bundle = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'oracle', '_ref', 'refbundle')
+    if os.path.isdir(os.path.join(ref, 'ldm')):
+        root, origin = ref, 'sources'
+    elif os.path.exists(os.path.join(bundle, 'ldm', 'modules', 'diffusionmodules', 'openaimodel.pyc')):
+        root, origin = bundle, 'bytecode bundle oracle/_ref/refbundle'
+    else:
+        return None, None
     try:
         from oracle.make_golden import _import_reference
         from oracle.plan import SD_V1
         from oracle.weights import make_state_dict
-        UNetModel = _import_reference()[0]
+        UNetModel = _import_reference(root)[0]
         m = UNetModel(**SD_V1.ref_kwargs()).eval()
         m.load_state_dict(make_state_dict(SD_V1, 0), strict=True)
-        return lambda x, t, c: m(x, t, context=c)
+        return (lambda x, t, c: m(x, t, context=c)), origin
     except Exception as e:        # a missing dependency of the reference: fall back to the restatement, and say so
         print(f'[bench] reference UNet not importable ({type(e).__name__}: {e}); CPU baseline uses the oracle port', file=sys.stderr)
-        return None
+        return None, None
 
 
 def cpu_baseline(n_unet_calls=2):
@@ -410,7 +417,7 @@ def cpu_baseline(n_unet_calls=2):
     cores = usable_cores()
     torch.set_num_threads(cores)
     x, t, ctx = make_inputs(SD_V1, 2, 64, 64, seed=1)
-    ref_fn = reference_unet()
+    ref_fn, ref_origin = reference_unet()
     kind = 'reference' if ref_fn is not None else 'port'
     if ref_fn is None:
         sd = make_state_dict(SD_V1, 0)
@@ -430,7 +437,7 @@ def cpu_baseline(n_unet_calls=2):
     vae_ref.decode_first_stage(vsd, vae_ref.SD_VAE, z)
     t_vae = time.perf_counter() - t0
     s_per_image = 51 * t_unet + t_vae
-    who = 'reference UNetModel' if kind == 'reference' else 'oracle UNet'
+    who = f'reference UNetModel ({ref_origin})' if kind == 'reference' else 'oracle UNet'
     return {'value': 1.0 / s_per_image, 'unit': 'images/s', 'cores': cores, 'kind': kind,
             'sample': f'{len(times)} {who} call(s) (fp32, {cores} threads, B=2, 64x64 latent: {t_unet:.2f} s each) + 1 VAE decode '
                       f'({t_vae:.2f} s), extrapolated to 51 calls + 1 decode = {s_per_image:.1f} s/image'}
@@ -480,7 +487,7 @@ def main():
                     help='txt2img512 = BASELINE.json configs[1] (the headline metric, default); txt2img768 = configs[3]; '
                          'img2img512 = configs[4]')
     ap.add_argument('--traffic-pass', action='store_true',
-                    help='measure HBM bytes per launch with rocprofv3 PMC passes and write profiles/traffic_r05.json (then exit)')
+                    help='measure HBM bytes per launch with rocprofv3 PMC passes and write profiles/traffic_r06.json (then exit)')
     ap.add_argument('--traffic-out', default=None, help='second copy of the --traffic-pass JSON (e.g. under gpurun_out/)')
     ap.add_argument('--cpu-baseline-only', action='store_true', help='time only the CPU comparator (no GPU needed) and exit')
     args = ap.parse_args()
@@ -571,18 +578,32 @@ def main():
                 # +13 % vs rocprofv3 kernel durations).  The table is therefore SCALED by (un-profiled call) / (sum of the event-timed
                 # classes) -- the figure that agrees with `rocprofv3 --kernel-trace --stats` of the same call to ~2 % -- and the raw
                 # event figures are kept beside it (`*_events`).
+                # the event overhead is roughly CONSTANT per launch, so a uniform scale over-corrects the long GEMM launches
+                # and under-corrects the short helpers.  Round 6: the primary correction subtracts one constant per launch,
+                # c = (sum of event-timed launches - un-profiled call) / launches; the uniformly scaled and the raw figures stay beside it.
                 ev_sum = sum(r['ms'] for r in table)
+                n_launch = sum(r['launches'] for r in table)
                 ev_scale = min(1.0, ms / ev_sum) if ev_sum > 0 else 1.0
+                ev_const = max(0.0, (ev_sum - ms) / n_launch) if n_launch else 0.0
                 for r in table:
                     r['ms_events'] = r['ms']
-                    r['ms'] = r['ms'] * ev_scale
+                    r['ms_scaled'] = r['ms'] * ev_scale
+                    r['ms'] = max(r['ms'] - ev_const * r['launches'], 0.25 * r['ms'])
+                # the st_mid chain launch runs the cross-attention too: its attention flops do not belong to the GEMM family
+                for r in table:
+                    if r['name'].startswith('st_mid_ctx'):
+                        gemm_fl = r['launches'] * 2.0 * (2 * LAT * LAT) * (2.0 * 320 * 320)
+                        r['flops_attn'] = max(0.0, r['flops'] - gemm_fl)
+                        r['flops'] = min(r['flops'], gemm_fl)
+                        if 'flops_exec' in r:
+                            r['flops_exec'] = max(0.0, r['flops_exec'] - r['flops_attn'])
                 fam = [r for r in table if r['name'].startswith(GEMM_CLASSES)]
                 dom = {'name': 'igemm_kernel / conv3halo_kernel / gemm_split16_kernel / ff_tail_kernel / st_head_kernel (the GEMM family: one MFMA core + shared epilogue, all tile instantiations; the row-strip chain kernels run 2-4 of the reference GEMMs per launch)',
                        'launches': sum(r['launches'] for r in fam), 'ms': sum(r['ms'] for r in fam),
                        'flops': sum(r['flops'] for r in fam), 'flops_exec': sum(r.get('flops_exec', r['flops']) for r in fam),
                        'bytes': sum(r['bytes'] for r in fam)}
                 top = fam[0]
-                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(GEMM_CLASSES + ('attn',))]
+                mfma = [r for r in table if r['flops'] > 0 and r['name'].startswith(GEMM_CLASSES + ('attn',))]      # (st_mid_ctx: GEMM flops only)
                 # `flops` are ALGORITHMIC (2 x MACs of the reference's convs / linears); the 3-pass split-fp16
                 # 1x1 convs execute 3x theirs, which only `achieved_executed` / `frac_executed` count
                 ach = dom['flops'] / (dom['ms'] * 1e-3) / 1e12
@@ -593,9 +614,13 @@ def main():
                 out['roofline'] = {
                     'bound': 'mfma', 'kernel': dom['name'], 'launches_per_unet_call': dom['launches'],
                     'avg_launch_ms': dom['ms'] / dom['launches'],
-                    'avg_launch_ms_events': dom['ms'] / dom['launches'] / ev_scale,
-                    'timing': f'per-launch HIP events on the launch stream, scaled by {ev_scale:.4f} = un-profiled UNet call ({ms:.3f} ms) / sum of '
-                              f'the event-timed launches ({ev_sum:.3f} ms); compare with rocprofv3 --kernel-trace --stats (profiles/kernel_stats_bench_r05.txt)',
+                    'avg_launch_ms_events': sum(r['ms_events'] for r in fam) / dom['launches'],
+                    'avg_launch_ms_scaled': sum(r['ms_scaled'] for r in fam) / dom['launches'],
+                    'frac_events': dom['flops'] / (sum(r['ms_events'] for r in fam) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                    'frac_scaled': dom['flops'] / (sum(r['ms_scaled'] for r in fam) * 1e-3) / 1e12 / MFMA_PEAK_TFLOPS,
+                    'timing': f'per-launch HIP events on the launch stream minus a constant {ev_const * 1e3:.2f} us per launch = (sum of the event-timed '
+                              f'launches ({ev_sum:.3f} ms) - un-profiled UNet call ({ms:.3f} ms)) / {n_launch} launches; frac_events = raw events, '
+                              f'frac_scaled = round 5\'s uniform scale {ev_scale:.4f}; compare with rocprofv3 --kernel-trace --stats (profiles/kernel_stats_bench_r06.txt)',
                     'achieved': ach, 'peak': MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s', 'frac': ach / MFMA_PEAK_TFLOPS,
                     'achieved_executed': ach_exec, 'frac_executed': ach_exec / MFMA_PEAK_TFLOPS,
                     'algorithmic_gflop_per_launch': dom['flops'] / dom['launches'] / 1e9,

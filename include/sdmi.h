@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SDMI_ABI_VERSION 16
+#define SDMI_ABI_VERSION 17
 
 typedef struct sdmi_unet sdmi_unet;
 

@@ -22,8 +22,9 @@ sys.path.insert(0, ROOT)
 REF = os.environ.get('SD_REFERENCE', '/root/reference')
 
 
-def _import_reference():
-    sys.path.insert(0, REF)
+def _import_reference(root=None):
+    """`root`: a reference checkout, or the sourceless bytecode bundle of oracle/build_ref_bundle.py (oracle/_ref/refbundle)."""
+    sys.path.insert(0, root or REF)
     om = types.ModuleType('omegaconf')
     lc = types.ModuleType('omegaconf.listconfig')
 
@@ -85,6 +86,17 @@ def main():
         ('sdv1_b6_16x16', SD_V1, 0, 6, 16, 16, 77),          # t = (981, 481, 1, 741, 981, 481)
         ('tiny_b6_16x16', TINY, 0, 6, 16, 16, 77),
         ('tiny_b10_8x8', TINY, 0, 10, 8, 8, 77),             # > 8 rows: UNetModelHIP.forward chunks (n_samples = 5)
+        # round 6: the parity claim must not rest on ONE weight draw from ONE benign distribution.
+        # (a) two more draws of the uniform family at the three latent sizes that exercise every level's shapes
+        ('sdv1_w1_16x16', SD_V1, 1, 2, 16, 16, 77), ('sdv1_w1_32x32', SD_V1, 1, 2, 32, 32, 77), ('sdv1_w1_64x64', SD_V1, 1, 2, 64, 64, 77),
+        ('sdv1_w2_16x16', SD_V1, 2, 2, 16, 16, 77), ('sdv1_w2_32x32', SD_V1, 2, 2, 32, 32, 77), ('sdv1_w2_64x64', SD_V1, 2, 2, 64, 64, 77),
+        # (b) the 'realistic' family (oracle/weights.py): Student-t weights, x8 outlier rows / gammas, context outlier channels at
+        #     |x| ~ 30, x_t at the t = 981 (white noise) and t = 1 (nearly clean latent) scales in one batch
+        ('sdv1_real_16x16', SD_V1, 0, 2, 16, 16, 77, (981, 1), 'realistic'),
+        ('sdv1_real_32x32', SD_V1, 0, 2, 32, 32, 77, (981, 1), 'realistic'),
+        ('sdv1_real_64x64', SD_V1, 0, 2, 64, 64, 77, (981, 1), 'realistic'),
+        ('sdv1_real1_16x16', SD_V1, 1, 2, 16, 16, 77, (481, 1), 'realistic'),
+        ('tiny_real_16x16', TINY, 0, 2, 16, 16, 77, (981, 1), 'realistic'),      # CPU-suite sized twin (oracle == reference)
     ]
     only = [a for a in sys.argv[1:] if not a.startswith('-')]
     if only:
@@ -92,17 +104,18 @@ def main():
     ref_models = {}
     for name, cfg, wseed, b, h, w, L, *rest in cases:
         tsteps = rest[0] if rest else (981, 481, 1, 741)
-        key = (cfg, wseed)
+        style = rest[1] if len(rest) > 1 else 'uniform'
+        key = (cfg, wseed, style)
         if key not in ref_models:
             ref_models.clear()  # keep memory bounded
-            sd = make_state_dict(cfg, wseed)
+            sd = make_state_dict(cfg, wseed, style=style)
             m = UNetModel(**cfg.ref_kwargs()).eval()
             missing = m.load_state_dict(sd, strict=True)
             n_params = sum(p.numel() for p in m.parameters())
             print(f'[{name}] reference UNetModel loaded strict=True: {len(sd)} tensors, {n_params} params', flush=True)
             ref_models[key] = (m, sd)
         m, sd = ref_models[key]
-        x, t, ctx = make_inputs(cfg, b, h, w, seed=1, ctx_len=L, timesteps=tsteps)
+        x, t, ctx = make_inputs(cfg, b, h, w, seed=1, ctx_len=L, timesteps=tsteps, style=style)
         with torch.no_grad():
             eps_ref = m(x, t, context=ctx)
         taps = {}
@@ -113,7 +126,7 @@ def main():
         assert err < 2e-5, f'oracle restatement differs from reference: {err}'
         np.savez_compressed(os.path.join(out_dir, f'unet_{name}.npz'),
                             eps=eps_ref.numpy().astype(np.float32),
-                            weight_seed=wseed, input_seed=1, batch=b, h=h, w=w, ctx_len=L,
+                            weight_seed=wseed, style=style, input_seed=1, batch=b, h=h, w=w, ctx_len=L,
                             t=t.numpy(), eps_absmax=float(eps_ref.abs().max()),
                             oracle_vs_reference=err)
     ref_models.clear()

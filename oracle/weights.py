@@ -81,16 +81,44 @@ def param_specs(cfg: UNetConfig):
     return specs
 
 
-def make_state_dict(cfg: UNetConfig, seed: int = 0, dtype=torch.float32):
-    """Deterministic (torch CPU generator) synthetic weights."""
+def _student_t4(shape, g):
+    """Student-t, nu = 4, unit variance: z / sqrt(chi2_4 / 4) / sqrt(2).  Only randn, +, *, sqrt and / (IEEE-exact ops on top
+    of the generator), so the draw is reproducible on another host exactly like the randn-based tensors are."""
+    z = torch.randn(shape, generator=g, dtype=torch.float32)
+    c = torch.zeros(shape, dtype=torch.float32)
+    for _ in range(4):
+        c += torch.randn(shape, generator=g, dtype=torch.float32).square_()
+    return z / (c * 0.25).sqrt_() * (1.0 / math.sqrt(2.0))
+
+
+STYLES = ('uniform', 'realistic')
+OUTLIER_FRACTION = 0.01     # 'realistic': share of output channels / norm channels with the gain below
+OUTLIER_GAIN = 8.0
+
+
+def make_state_dict(cfg: UNetConfig, seed: int = 0, dtype=torch.float32, style: str = 'uniform'):
+    """Deterministic (torch CPU generator) synthetic weights.
+
+    style 'uniform' (rounds 1-5): uniform +-1/sqrt(fan_in) weights, gamma = 1 + 0.1 N.
+    style 'realistic' (round 6): what trained checkpoints have and the benign draw does not --
+    heavy-tailed weights (Student-t, nu = 4, the SAME variance 1/(3 fan_in)), 1 % of the output channels of every
+    conv / linear with a x8 gain on their weight rows, 1 % of every norm's channels with a x8 gamma."""
+    assert style in STYLES, style
     g = torch.Generator().manual_seed(seed)
+    real = style == 'realistic'
     sd = OrderedDict()
     for key, shape, kind in param_specs(cfg):
         if kind in ('w', 'wz'):
             fan_in = 1
             for s in shape[1:]:
                 fan_in *= s
-            if kind == 'w':
+            if real:
+                std = math.sqrt(1.0 / (3.0 * fan_in)) if kind == 'w' else 0.5 / math.sqrt(fan_in)
+                t = _student_t4(shape, g) * std
+                rows = torch.rand(shape[0], generator=g) < OUTLIER_FRACTION
+                if kind == 'w' and shape[0] >= 64:
+                    t[rows] *= OUTLIER_GAIN
+            elif kind == 'w':
                 bound = 1.0 / math.sqrt(fan_in)
                 t = (torch.rand(shape, generator=g, dtype=torch.float32) * 2 - 1) * bound
             else:
@@ -99,6 +127,8 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, dtype=torch.float32):
             t = torch.randn(shape, generator=g, dtype=torch.float32) * 0.02
         elif kind == 'gamma':
             t = 1.0 + 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
+            if real:
+                t[torch.rand(shape[0], generator=g) < OUTLIER_FRACTION] *= OUTLIER_GAIN
         elif kind == 'beta':
             t = 0.1 * torch.randn(shape, generator=g, dtype=torch.float32)
         else:
@@ -108,10 +138,25 @@ def make_state_dict(cfg: UNetConfig, seed: int = 0, dtype=torch.float32):
 
 
 def make_inputs(cfg: UNetConfig, batch: int, h: int, w: int, seed: int = 1, ctx_len: int = 77,
-                timesteps=(981, 481, 1, 741)):
-    """Seeded (x_t, t, context) triple; different context per batch row (SURVEY 8c hygiene 4)."""
+                timesteps=(981, 481, 1, 741), style: str = 'uniform'):
+    """Seeded (x_t, t, context) triple; different context per batch row (SURVEY 8c hygiene 4).
+
+    style 'realistic': the context carries three outlier channels at |x| ~ 30 on every token (what CLIP ViT-L/14's
+    last_hidden_state has) over unit-variance channels; rows whose timestep is < 500 get an x_t at the scale and
+    smoothness of a nearly clean latent (a low-resolution field upsampled x4, std ~ 0.9, plus sqrt(1 - a_t)-sized noise)
+    instead of white noise."""
+    assert style in STYLES, style
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(batch, cfg.in_channels, h, w, generator=g)
     ctx = torch.randn(batch, ctx_len, cfg.context_dim, generator=g)
     t = torch.tensor([timesteps[i % len(timesteps)] for i in range(batch)], dtype=torch.int64)
+    if style == 'realistic':
+        ch = torch.randperm(cfg.context_dim, generator=g)[:3]
+        sign = torch.tensor([1.0, -1.0, 1.0])
+        ctx[:, :, ch] = ctx[:, :, ch] * 1.5 + 30.0 * sign
+        lo = torch.randn(batch, cfg.in_channels, (h + 3) // 4, (w + 3) // 4, generator=g) * 0.9
+        smooth = lo.repeat_interleave(4, 2).repeat_interleave(4, 3)[:, :, :h, :w]
+        for i in range(batch):
+            if int(t[i]) < 500:
+                x[i] = smooth[i] + 0.05 * x[i]
     return x, t, ctx

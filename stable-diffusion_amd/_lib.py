@@ -160,7 +160,7 @@ def load():
             fn = getattr(lib, name)      # AttributeError here = header / library mismatch
             fn.restype = res
             fn.argtypes = args
-        if lib.sdmi_abi_version() != 16:
+        if lib.sdmi_abi_version() != 17:
             raise SdmiError('libsdmi ABI version mismatch')
         _lib = lib
     return _lib

@@ -734,6 +734,7 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
+  SDMI_CHECK((int64_t)p.M < (int64_t)65536 * p.Hout * p.Wout, "fast_div_hw: at most 65535 samples per launch");
   q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   q.magic_w2 = div_magic(p.Wout + 2);
@@ -802,6 +803,7 @@ int launch_halo_gn_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
+  SDMI_CHECK((int64_t)p.M < (int64_t)65536 * p.Hout * p.Wout, "fast_div_hw: at most 65535 samples per launch");
   q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   q.magic_w2 = div_magic(p.Wout + 2);

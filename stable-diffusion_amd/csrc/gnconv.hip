@@ -343,6 +343,7 @@ int launch_gn_conv3(const GnConvParams& p, hipStream_t stream) {
 #endif
   q.epi.splitk = 1; q.epi.splitk_fused = 0; q.epi.slab_tiled = 0;
   q.epi.epi_vec = epi_vec_ok(e);
+  SDMI_CHECK((int64_t)e.M < (int64_t)65536 * e.Hout * e.Wout, "fast_div_hw: at most 65535 samples per launch");
   q.epi.magic_hw = div_magic_hw(e.Hout * e.Wout);
   q.epi.magic_w = div_magic(e.Wout);
   for (int t = 0; t < e.gn_n; ++t) q.epi.gn_magic[t] = div_magic(e.gn_cpg[t]);

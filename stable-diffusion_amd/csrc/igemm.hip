@@ -333,8 +333,12 @@ __device__ __forceinline__ TiledQuad tiled_quad(const IGemmParams& p, int q, int
 // are folded exactly as norm.hip's apply kernel folds them (gn_mean_rstd over the eight slots) and the quad still sitting in registers is
 // normalised with gn_apply_elem: the same fp16 bits as the two launches.  A spin that runs out (cannot happen with a resident grid) stores
 // NaNs: loud, not a hang.
-// (COOP workgroups are 1024 threads: the tickets of a grid all land on ONE address, and device-scope atomics on one address retire
-// at ~25 ns each -- 640 workgroups of 256 threads spent 16 us at the barrier, profiles/reduce_gn_coop_r05.txt)
+// (COOP workgroups are 1024 threads: round 5's barrier put the tickets of a grid on ONE address, where device-scope atomics retire
+// at ~25 ns each -- 640 workgroups of 256 threads spent 16 us at the barrier, profiles/reduce_gn_coop_r05.txt; round 6: hierarchical, see below)
+#ifndef SDMI_REDUCE_GN_XCD_DEFAULT
+#define SDMI_REDUCE_GN_XCD_DEFAULT 0
+#endif
+constexpr int COOP_BAR_INTS = 18 * 32;            // the grid barrier's words (see below)
 template <bool COOP>
 __global__ void __launch_bounds__(COOP ? 1024 : 256) splitk_reduce_tiled_kernel(IGemmParams p, int nsplit) {
   constexpr int NWV = COOP ? 16 : 4;                              // waves per workgroup (at most)
@@ -408,18 +412,30 @@ __global__ void __launch_bounds__(COOP ? 1024 : 256) splitk_reduce_tiled_kernel(
     __shared__ float2 s_tab[NWV][4];                      // [wave][group - first group of the wave's 32 columns] {mean, rstd}
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int* const cnt = p.splitk_cnt + p.splitk_cnt_ints - 2;              // {tickets, departures}: zero between launches
-    const int nblk = (int)gridDim.x;
+    // Round 6: the HIERARCHICAL barrier (MI355X_MICROARCH.md price list, "barrier-xcd" instead of "barrier-counter": round 5 put every ticket of the
+    // grid on ONE address and let every workgroup poll it: 8 - 16 us).  Workgroups form eight groups by blockIdx % 8 (the dispatcher's XCD
+    // round-robin -- used for speed only; the populations are static, so any placement is correct).  A workgroup arrives on its GROUP's counter
+    // (<= 32 arrivals per address, eight addresses in parallel); the last arriver of a group arrives on the TOP counter; the last of those resets
+    // the counters and stores the call-local epoch into the eight RELEASE words.  Nobody polls a counter: every workgroup polls its group's
+    // release word (<= 32 relaxed pollers per line, no atomics on it).  The payload (the statistics) is written by device-scope atomics and read
+    // back by agent-scope loads, so the barrier needs no release / acquire fence -- arrival counting is all of it.
+    // Words (128-byte lines, the tail of the tile-counter region, zeroed by the per-call memset): line g < 8: group counter, line 8: top counter,
+    // line 9: epoch of the previous barrier in this call, line 10 + g: release word of group g.
+    int* const blk = p.splitk_cnt + p.splitk_cnt_ints - COOP_BAR_INTS;
+    const int nblk = (int)gridDim.x, ngrp = min(nblk, 8);
     if (tid == 0) {
-      __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      int budget = 1 << 16, seen = 0;
-      while ((seen = __hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) < nblk && --budget > 0) __builtin_amdgcn_s_sleep(4);
-      s_ok = seen >= nblk;
-      // the last one to leave zeroes the pair for the next launch (launches of a stream do not overlap)
-      if (__hip_atomic_fetch_add(cnt + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nblk - 1) {
-        __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cnt + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int g = (int)blockIdx.x & 7, pop = (nblk - g + 7) >> 3;
+      const int ep = __hip_atomic_load(blk + 9 * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;      // (written by the previous launch's last leader)
+      if (__hip_atomic_fetch_add(blk + g * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == pop - 1) {
+        if (__hip_atomic_fetch_add(blk + 8 * 32, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp - 1) {
+          for (int j = 0; j <= 8; ++j) __hip_atomic_store(blk + j * 32, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(blk + 9 * 32, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          for (int j = 0; j < ngrp; ++j) __hip_atomic_store(blk + (10 + j) * 32, ep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
+      int budget = 1 << 16, seen = 0;
+      while ((seen = __hip_atomic_load(blk + (10 + g) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != ep && --budget > 0) __builtin_amdgcn_s_sleep(2);
+      s_ok = seen == ep;
     }
     __syncthreads();
     // ---- {mean, rstd} of the (at most four) groups this wave's 32 columns touch: lanes 8 k .. 8 k + 7 fold the eight slots of group gfirst + k
@@ -529,20 +545,16 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     if (p.gn_n > 0) SDMI_CHECK((p.Hout * p.Wout) % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
     // the consuming GroupNorm (+ SiLU) applied by the reduction itself, behind a grid barrier (splitk_reduce_tiled_kernel<true>): where
     // that GroupNorm's statistics come from this very reduction, channels-per-group % 4 == 0 and the whole grid is resident at once
-    // (one workgroup of 1024 threads per CU at most: <= 256 workgroups).  Experiments build, SDMI_REDUCE_GN_COOP=1 (the same bits; measured slower).
-#ifndef SDMI_EXPERIMENTS
-    constexpr bool coop = false;       // (measured slower: a device-scope grid barrier costs 8 - 16 us here, profiles/reduce_gn_coop_r05.txt)
-#else
-    const bool coop = env_int("SDMI_REDUCE_GN_COOP", 0) && p.pgn_out && p.pgn_gamma && p.pgn_beta && p.mode == EPI_PLAIN && p.gn_n == 1 &&
+    // (one workgroup of 1024 threads per CU at most: <= 256 workgroups).  Round 5: experiments build, one ticket counter (measured slower).
+    // Round 6: product build, run-time switch SDMI_REDUCE_GN_XCD (read per launch: the tests flip it between two forwards).
+    const bool coop = env_int("SDMI_REDUCE_GN_XCD", SDMI_REDUCE_GN_XCD_DEFAULT) && p.pgn_out && p.pgn_gamma && p.pgn_beta && p.mode == EPI_PLAIN && p.gn_n == 1 &&
                       p.gn_cbase[0] == 0 && p.gn_cpg[0] == p.N / 32 && p.N % 128 == 0 && p.N / 32 >= 16 && p.M == p.B * p.Hout * p.Wout &&
-                      (p.Hout * p.Wout) % 32 == 0 && !p.out_f16 && !p.out_lo && !p.ln_out && p.splitk_cnt && p.splitk_cnt_ints >= 2 &&
+                      (p.Hout * p.Wout) % 32 == 0 && !p.out_f16 && !p.out_lo && !p.ln_out && p.splitk_cnt && p.splitk_cnt_ints >= COOP_BAR_INTS &&
                       quads % 1024 == 0 && quads / 1024 <= 256 && (!p.pgn_keep_f32 || (p.out_f32 && p.ldo % 4 == 0));
-#endif
     ProfScope pst(coop ? "splitk_reduce_gn" : "splitk_reduce", 0.0, coop ? mn * (4.0 * nsplit + 2.0 + (p.pgn_keep_f32 ? 4.0 : 0.0)) : mn * 4.0 * (nsplit + 1), stream);
     // threads per block: 256, or 128 where that still leaves fewer than two blocks per CU (SDMI_REDUCE_BLOCK: 0 auto, 128 / 256 forced; A/B)
     const int rb_env = env_int("SDMI_REDUCE_BLOCK", 256);
     const int rb = (rb_env == 128 || (rb_env == 0 && quads / 256 < 512)) ? 128 : 256;
-#ifdef SDMI_EXPERIMENTS
     if (coop) {
       hipLaunchKernelGGL(splitk_reduce_tiled_kernel<true>, dim3((unsigned)(quads / 1024)), dim3(1024), 0, stream, p, nsplit);
       SDMI_HIP_OK(hipGetLastError());
@@ -551,7 +563,6 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
       if (range_check_enabled() && range_scan("GroupNorm fp16 output (split-K reduction)", p.pgn_out, (int64_t)p.M * p.N, stream)) return -1;
       return 0;
     }
-#endif
     hipLaunchKernelGGL(splitk_reduce_tiled_kernel<false>, dim3((unsigned)(quads / rb)), dim3(rb), 0, stream, p, nsplit);
     SDMI_HIP_OK(hipGetLastError());
     pst.end();

@@ -679,7 +679,11 @@ static int tile_order_n_fastest(const IGemmParams& p) {
 // into the GEMM (see igemm_epilogue) or the slabs are tiled (IGemmParams::slab_tiled), [split][M][N] otherwise
 static bool splitk_fusable(const IGemmParams& p, int bm, int bn) {
   // default off: same-box A/B (profiles/splitk_fused_r02.txt) has the separate reduce kernel ahead, 3.23 vs 3.16 images/s
+#ifdef SDMI_EXPERIMENTS
   static const int env_fused = env_int("SDMI_SPLITK_FUSED", 0);
+#else
+  constexpr int env_fused = 0;
+#endif
   return env_fused && p.splitk_cnt && (int64_t)cdiv(p.M, bm) * cdiv(p.N, bn) <= p.splitk_cnt_ints;
 }
 // rows per block of splitk_reduce_kernel: 32 (one row per thread) up to 256, doubling while the grid keeps >= 1024 blocks

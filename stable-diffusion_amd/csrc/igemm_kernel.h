@@ -348,6 +348,7 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   slab_layout(q, BM, BN, WARPS_M, WARPS_N, nsplit);
   q.epi_vec = epi_vec_ok(p);
   SDMI_CHECK(splitk_ws_need(p, BM, BN, nsplit) <= p.splitk_ws_floats, "split-K workspace too small");
+  SDMI_CHECK((int64_t)p.M < (int64_t)65536 * p.Hout * p.Wout, "fast_div_hw: at most 65535 samples per launch");
   q.magic_hw = div_magic_hw(p.Hout * p.Wout);
   q.magic_w = div_magic(p.Wout);
   for (int t = 0; t < p.gn_n; ++t) q.gn_magic[t] = div_magic(p.gn_cpg[t]);

@@ -44,9 +44,12 @@ int UNet::build(const sdmi_unet_cfg& c) {
   SDMI_CHECK(c.num_heads >= 1 && c.transformer_depth >= 1, "num_heads / transformer_depth");
   const int mc = c.model_channels;
   te_ = 4 * mc;
+#ifdef SDMI_EXPERIMENTS      // knobs that LOWER the arithmetic or lost their A/B: not read by the product library
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
-  if (const char* e = getenv("SDMI_FUSE_GN_STATS")) fuse_gn_stats_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_PRECISE_KV")) precise_kv_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_SIDE_STREAM")) side_stream_ = atoi(e) != 0;
+#endif
+  if (const char* e = getenv("SDMI_FUSE_GN_STATS")) fuse_gn_stats_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_LN_FOLD")) ln_fold_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_LN_FOLD_MIN_ROWS")) ln_fold_min_rows_ = atoi(e);
   const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
@@ -159,8 +162,12 @@ int UNet::build(const sdmi_unet_cfg& c) {
           expect(t + ".attn1.to_out.0.weight", {C, C}, W_ROWS16, (void**)&T.wo1, 0, (int)C);
           expect(t + ".attn1.to_out.0.bias", {C}, W_F32, (void**)&T.bo1);
           expect(t + ".attn2.to_q.weight", {C, C}, W_ROWS16, (void**)&T.wq2, 0, (int)C);
-          expect(t + ".attn2.to_k.weight", {C, CD}, W_ROWS16, (void**)&T.wkv2, 0, (int)CD);
-          expect(t + ".attn2.to_v.weight", {C, CD}, W_ROWS16, (void**)&T.wkv2, (int)C, (int)CD);
+          // round 6: the context K / V projections as 3-pass split-fp16 (k_hi w_hi + k_lo w_hi + k_hi w_lo, one K-concatenated GEMM): the
+          // context is the one operand of the call with channel outliers by construction (CLIP's last_hidden_state has channels at
+          // |x| ~ 30) and its fp16 rounding was the error class that grew most (11x) on the outlier goldens (tools/precision_emul.py);
+          // computed once per prompt and cached for all 51 calls, so the extra passes cost nothing per UNet call
+          expect(t + ".attn2.to_k.weight", {C, CD}, precise_kv_ ? W_SPLIT3_ROWS : W_ROWS16, (void**)&T.wkv2, 0, (int)CD);
+          expect(t + ".attn2.to_v.weight", {C, CD}, precise_kv_ ? W_SPLIT3_ROWS : W_ROWS16, (void**)&T.wkv2, (int)C, (int)CD);
           expect(t + ".attn2.to_out.0.weight", {C, C}, W_ROWS16, (void**)&T.wo2, 0, (int)C);
           expect(t + ".attn2.to_out.0.bias", {C}, W_F32, (void**)&T.bo2);
           expect(t + ".ff.net.0.proj.weight", {8 * C, C}, W_GEGLU_W, (void**)&T.wgg);
@@ -255,6 +262,7 @@ size_t UNet::slot_bytes(const WeightSlot& s) const {
     case W_F32_ROWS: return (size_t)emb_total_ * s.ld * sizeof(float);
     case W_CONV: case W_GEGLU_W: return numel * sizeof(f16);
     case W_SPLIT3: return 3 * numel * sizeof(f16);
+    case W_SPLIT3_ROWS: return 2 * 3 * numel * sizeof(f16);      // (to_k | to_v share one [2C][3 K] buffer)
     case W_ROWS16: {
       size_t total_rows = (size_t)s.shape[0];
       if (s.key.find(".attn1.to_") != std::string::npos && s.key.find("to_out") == std::string::npos) total_rows *= 3;
@@ -298,6 +306,10 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
     case W_SPLIT3:
       rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_split3(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], stream);
+      break;
+    case W_SPLIT3_ROWS:  // rows [row0, row0 + rows) of a split-fp16 [*][3 ld] matrix
+      rc = dev_alloc(s.dst, slot_bytes(s));
+      if (!rc) rc = launch_pack_split3(dptr, (f16*)*s.dst + (size_t)s.row0 * 3 * s.ld, (int)shape[0], (int)shape[1], stream);
       break;
     case W_CONV_OUT:
       rc = dev_alloc(s.dst, slot_bytes(s));
@@ -417,6 +429,7 @@ int UNet::export_packed(void* host_buf, int64_t bytes, hipStream_t stream) {
   PackedHeader h{};
   memcpy(h.magic, "SDMIPK01", 8);
   h.abi = SDMI_ABI_VERSION; h.precise_1x1 = precise_1x1_ ? 1 : 0; h.n_buffers = (int32_t)bufs.size(); h.cfg = cfg_;
+  h.reserved = precise_kv_ ? 1 : 0;      // (ABI 17: split-fp16 context K / V weights)
   h.total_bytes = total;
   memcpy(host_buf, &h, sizeof(h));
   int64_t off = (int64_t)round_up((int64_t)sizeof(PackedHeader), PK_ALIGN);
@@ -436,6 +449,7 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
   SDMI_CHECK(h.abi == SDMI_ABI_VERSION, "packed blob was written by a different ABI version: repack it");
   SDMI_CHECK(memcmp(&h.cfg, &cfg_, sizeof(cfg_)) == 0, "packed blob was written for a different UNet configuration");
   SDMI_CHECK((h.precise_1x1 != 0) == precise_1x1_, "packed blob was written with a different SDMI_PRECISE_1X1 setting");
+  SDMI_CHECK((h.reserved != 0) == precise_kv_, "packed blob was written with a different SDMI_PRECISE_KV setting");
   std::vector<std::pair<void**, size_t>> bufs;
   int64_t total = 0;
   packed_layout(&bufs, &total);
@@ -476,6 +490,7 @@ struct Fwd : FwdBase {
   float* emb_all = nullptr;     // [B][emb_total] (emb_ld = emb_total), or one row of the timestep table shared by every sample (emb_ld = 0)
   int emb_ld = 0;
   const f16* ctx16 = nullptr;   // [B*L][context_dim], null when the cached K/V are used
+  const f16* ctx16_lo = nullptr; // ... its split-fp16 low half fp16(ctx - fp16(ctx)) (precise K / V projections)
 
   // conv3x3(SiLU(GroupNorm32(cat(x0, x1)))) with the normalisation folded into the convolution's halo staging
   // (openaimodel.py:201-204,225-231): statistics first (from the producers' epilogues when the plan has them), then ONE launch
@@ -590,7 +605,11 @@ struct Fwd : FwdBase {
   void context_kv(Layer& L, int d) {
     TBlock& T = L.tb[d];
     const int C = L.cin, Lp = (int)round_up(Lctx, 8);
-    IGemmParams p = dense(ctx16, B * Lctx, u->cfg_.context_dim, T.wkv2, 2 * C, Lctx);
+    const int CD = u->cfg_.context_dim;
+    IGemmParams p = dense(ctx16, B * Lctx, CD, T.wkv2, 2 * C, Lctx);
+    if (ctx16_lo) {          // split-fp16: A' = [hi | lo | hi] against W' = [hi | hi | lo]
+      p.a1 = ctx16_lo; p.c1 = CD; p.lda1 = CD; p.a2 = ctx16; p.c2 = CD; p.lda2 = CD; p.K = 3 * CD; p.k_alg = CD;
+    }
     p.mode = EPI_HEADS; p.seg_dst[0] = T.ck; p.seg_dst[1] = T.cvt; p.seg_kind[0] = 0; p.seg_kind[1] = 1;
     p.heads = L.heads; p.dh = L.dh; p.ntok = Lctx; p.ntok_pad = Lp; p.segC = C; p.splitk = 1;
     if (!dry && !rc && Lp != Lctx) {
@@ -972,13 +991,14 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
     const int mc = cfg_.model_channels;
     if (f.begin_pass((int64_t)12 << 20)) return -1;    // 48 MB of fp32 split-K slabs (largest user: 8 x 512 x 1280)
     f16* ctx16 = f.P<f16>((size_t)B * Lctx * cfg_.context_dim);
+    f16* ctx16_lo = precise_kv_ ? f.P<f16>((size_t)B * Lctx * cfg_.context_dim) : nullptr;
     const bool have_ctx = (ctx != nullptr) || d;
     if (have_ctx) {
-      if (!d) { int r = launch_cast_f16(ctx, ctx16, nullptr, (int64_t)B * Lctx * cfg_.context_dim, stream); if (r) return r; }
-      f.ctx16 = ctx16;
+      if (!d) { int r = launch_cast_f16(ctx, ctx16, ctx16_lo, (int64_t)B * Lctx * cfg_.context_dim, stream); if (r) return r; }
+      f.ctx16 = ctx16; f.ctx16_lo = ctx16_lo;
     } else {
       SDMI_CHECK(ctx_valid_, "ctx == NULL but no cached context for this (B, Lctx); call sdmi_unet_cache_context first");
-      f.ctx16 = nullptr;
+      f.ctx16 = nullptr; f.ctx16_lo = nullptr;
     }
     if (ctx_only) {
       auto each = [&](Layer& L) { if (L.kind == L_ATTN) for (int dd = 0; dd < (int)L.tb.size(); ++dd) f.context_kv(L, dd); };

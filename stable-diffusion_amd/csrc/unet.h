@@ -232,13 +232,13 @@ struct DevStage {
 };
 
 enum LayerKind { L_CONV_IN, L_RES, L_ATTN, L_DOWN, L_UP };
-enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B, W_SPLIT3 };
+enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B, W_SPLIT3, W_SPLIT3_ROWS };
 
 struct TBlock {   // BasicTransformerBlock (ldm/modules/attention.py:196-215)
   f16* wqkv = nullptr;   // [3C][C]   attn1 to_q | to_k | to_v
   f16* wo1 = nullptr; float* bo1 = nullptr;
   f16* wq2 = nullptr;    // [C][C]
-  f16* wkv2 = nullptr;   // [2C][context_dim]  attn2 to_k | to_v
+  f16* wkv2 = nullptr;   // attn2 to_k | to_v: [2C][3 context_dim] split-fp16 {hi | hi | lo} (round 6; [2C][context_dim] in the experiments build with SDMI_PRECISE_KV=0)
   f16* wo2 = nullptr; float* bo2 = nullptr;
   f16* wgg = nullptr; float* bgg = nullptr;     // GEGLU proj, rows interleaved (value32 | gate32)
   f16* wff2 = nullptr; float* bff2 = nullptr;
@@ -303,6 +303,7 @@ class UNet {
   // 1x1 convs on the residual stream (skip_connection, proj_in, proj_out) run as 3-pass split-fp16 GEMMs
   // (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): ~22-bit operands for 5 % of the FLOPs (DESIGN.md "precision")
   bool precise_1x1_ = true;
+  bool precise_kv_ = true;     // context K / V projections as 3-pass split-fp16 (round 6; see UNet::build)
   // ResBlock convs fold the GroupNorm + SiLU of their input into their halo staging (conv3halo.hip, conv3halo_gn_kernel) wherever
   // gn_fold_conv_supported() says so; SDMI_FUSE_GN_CONV=0 restores the GroupNorm-apply launches (A/B).
 

@@ -33,7 +33,9 @@ int Vae::build(const sdmi_vae_cfg& c, int parts) {
   SDMI_CHECK(c.in_channels >= 1 && c.in_channels <= 16 && c.z_channels >= 1 && c.z_channels <= 4 && c.embed_dim >= 1 &&
                  c.embed_dim <= 8 && c.out_ch >= 1 && c.out_ch <= 8,
              "in_channels <= 16, z_channels <= 4, embed_dim <= 8, out_ch <= 8 on this path");
+#ifdef SDMI_EXPERIMENTS
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
+#endif
   const int n = c.n_levels;
   auto res = [&](const std::string& p, int ci, int co) { VLayer L; L.kind = V_RES; L.prefix = p; L.cin = ci; L.cout = co; return L; };
   auto one = [&](VKind k, const std::string& p, int ch) { VLayer L; L.kind = k; L.prefix = p; L.cin = ch; L.cout = ch; return L; };

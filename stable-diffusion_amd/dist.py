@@ -35,10 +35,13 @@ def init_from_env(backend=None):
                 raise RuntimeError(f'LOCAL_RANK={local_rank} but this process sees {n_dev} GPU(s): launch one process per visible GPU')
             torch.cuda.set_device(local_rank)
             kw['device_id'] = torch.device('cuda', local_rank)
-        try:
-            dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
-        except TypeError:            # (a torch without the device_id keyword)
-            dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        if 'device_id' in kw:
+            # decided up front from the signature: a TypeError raised INSIDE a torch that accepts the keyword must
+            # propagate instead of silently restoring "RCCL guesses the device from the global rank"
+            import inspect
+            if 'device_id' not in inspect.signature(dist.init_process_group).parameters:
+                kw.pop('device_id')
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
         if backend == 'nccl' and torch.cuda.current_device() != local_rank:
             raise RuntimeError(f'rank {rank}: current device {torch.cuda.current_device()} != LOCAL_RANK {local_rank}')
         if dist.get_world_size() != world or dist.get_rank() != rank:

@@ -243,7 +243,6 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
     assert (other - outs[0]).abs().max().item() <= 4e-6 * ref.abs().max().item()
 
 
-@pytest.mark.experiments
 @pytest.mark.parametrize('B,H,W,C,N,splitk,tile,ksize,resid', [
     (2, 8, 8, 1280, 1280, 12, 19, 3, False),      # the 8x8 level: igemm 64x128, 12-way split (ResBlock conv1)
     (2, 16, 16, 1280, 1280, 10, 15, 3, False),    # 16x16: halo tile 256x128, 640 reduce workgroups
@@ -252,9 +251,9 @@ def test_igemm_splitk_sd_shapes(B, H, W, C, N, splitk, tile, fused):
     (1, 8, 8, 640, 512, 3, 5, 3, True),           # 16 channels per group (the narrowest accepted), one sample
 ])
 def test_igemm_splitk_reduce_groupnorm_behind_a_grid_barrier(B, H, W, C, N, splitk, tile, ksize, resid, monkeypatch):
-    """splitk_reduce_tiled_kernel<COOP> (experiments build, SDMI_REDUCE_GN_COOP=1): the split-K reduction applies the consuming GroupNorm(32) + SiLU itself, behind a grid
+    """splitk_reduce_tiled_kernel<COOP> (SDMI_REDUCE_GN_XCD=1; round 6: behind the hierarchical grid barrier): the split-K reduction applies the consuming GroupNorm(32) + SiLU itself, behind a grid
     barrier between producing the statistics and using them (sdmi_igemm_desc::pgn_*; openaimodel.py:225-231 at the split levels).
-    The statistics words must be the integers the plain reduction leaves (SDMI_REDUCE_GN_COOP=0), the fp16 output torch's GroupNorm + SiLU
+    The statistics words must be the integers the plain reduction leaves (SDMI_REDUCE_GN_XCD=0), the fp16 output torch's GroupNorm + SiLU
     within one rounding, the library's own statistics + apply kernels up to rounding flips (their statistics partition the same values
     differently; the bit-identity with the two-launch path is checked on whole UNet calls), ten bit-identical repeats."""
     g = _g(917)
@@ -276,7 +275,7 @@ def test_igemm_splitk_reduce_groupnorm_behind_a_grid_barrier(B, H, W, C, N, spli
     ga_d, be_d = gamma.to(DEV), beta.to(DEV)
 
     def run(coop, keep):
-        monkeypatch.setenv('SDMI_REDUCE_GN_COOP', coop)
+        monkeypatch.setenv('SDMI_REDUCE_GN_XCD', coop)
         o16 = torch.full((B * H * W, N), float('nan'), dtype=torch.float16, device=DEV)
         o32 = torch.full((B * H * W, N), float('nan'), device=DEV)
         acc = torch.zeros((B, 32, 8, 16), dtype=torch.int64, device=DEV)
@@ -523,6 +522,40 @@ def test_igemm_geglu():
         K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1, tile=tile)
         torch.cuda.synchronize()
         assert K.report(f'igemm geglu tile{tile}', out, ref, 4e-3) < 4e-3
+
+
+def test_gelu_erf_against_torch_erf():
+    """`gelu_erf` (igemm_dev.h) is Abramowitz-Stegun 7.1.26 with the hardware reciprocal and a sign copy -- pin it
+    against torch's exact-erf GELU (attention.py:43 `F.gelu`) THROUGH the GEGLU epilogue: one-hot operands make the accumulators
+    exactly (1, g), so the fp16 output is fp16(gelu(g)).  Stated tolerance: at most TWO fp16 ulps from fp16(torch gelu(g)) anywhere on the
+    gate range (measured: one ulp on 9 % of the gates, two only in the negative tail g < -4 where |gelu| < 1e-4 and the formula's 1.5e-7
+    absolute error is a visible fraction of the value), the right sign everywhere including |g| -> 0 (where a copysign of a slightly
+    negative erf would flip)."""
+    M, Kd, N = 4096, 64, 128
+    gate = torch.cat([torch.linspace(-8, 8, M - 64), torch.tensor([0.0, -0.0]), 10.0 ** -torch.arange(1, 32).float(),
+                      -(10.0 ** -torch.arange(1, 32).float())]).half()
+    a = torch.zeros((M, Kd), dtype=torch.float16)
+    a[:, 0] = 1.0
+    a[:, 1] = gate
+    w = torch.zeros((N, Kd))
+    w[:N // 2, 0] = 1.0           # value columns: 1
+    w[N // 2:, 1] = 1.0           # gate columns: g
+    wp, bp = K.pack_geglu(w.to(DEV), torch.zeros(N, device=DEV))
+    out = torch.full((M, N // 2), float('nan'), device=DEV, dtype=torch.float16)
+    K.igemm(a.to(DEV), wp, N, 1, M, 1, M, 1, bias=bp, out_f16=out, mode=1, tile=0)
+    torch.cuda.synchronize()
+    want = F.gelu(gate.double()).half()                  # exact erf in fp64, rounded once
+    got = out[:, 0].cpu()
+    assert torch.equal(out.cpu(), got[:, None].expand(-1, N // 2)), 'every column computes the same value'
+    def ordered(h):          # sign-magnitude fp16 bits -> a monotonic integer (+0 and -0 coincide)
+        b = h.view(torch.int16).int() & 0xffff
+        return torch.where(b >= 0x8000, -(b & 0x7fff), b)
+    ulps = (ordered(got) - ordered(want)).abs()
+    same_sign = (got.float() * want.float() >= 0) | (got == 0) | (want == 0)
+    print(f'[gelu_erf] {int((ulps > 0).sum())} of {M} gates differ from fp16(torch erf gelu); {int((ulps > 1).sum())} by more than one fp16 ulp; '
+          f'max {int(ulps.max())} ulp', flush=True)
+    big = gate.float().abs() < 4.0
+    assert bool(same_sign.all()) and int(ulps.max()) <= 2 and int(ulps[big].max()) <= 1 and torch.isfinite(got).all()
 
 
 @pytest.mark.parametrize('ntok,d,heads', [(64, 40, 8), (77, 32, 2), (16, 160, 8), (100, 80, 4)])

@@ -14,13 +14,14 @@ CFGS = {'tiny': TINY, 'small40': SMALL40, 'sdv1': SD_V1}
 
 
 @pytest.mark.parametrize('case', ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'tiny_b6_16x16',
-                                  'tiny_b10_8x8'])
+                                  'tiny_b10_8x8', 'tiny_real_16x16'])
 def test_oracle_unet_matches_reference_golden(case, golden_dir):
     z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
     cfg = CFGS[case.split('_')[0]]
-    sd = make_state_dict(cfg, int(z['weight_seed']))
+    style = str(z['style']) if 'style' in z.files else 'uniform'
+    sd = make_state_dict(cfg, int(z['weight_seed']), style=style)
     x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
-                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']), style=style)
     eps = unet_ref.unet_forward(sd, cfg, x, t, ctx)
     ref = torch.from_numpy(z['eps'])
     assert eps.shape == ref.shape

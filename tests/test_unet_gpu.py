@@ -21,18 +21,45 @@ TOL = 1e-3            # north_star: eps of the UNet vs the reference, max-abs --
 # the CPU suite (tests/test_oracle_golden.py: oracle == reference), and CFG batch 6 is held to the bar on the real
 # architecture by `sdv1_b6_16x16`; rows are independent (test_batch_rows_are_independent).)
 HEADROOM_WARN = 0.9e-3      # cases above this are listed by the test below: the margin a re-tune may eat
+# Round 6: goldens at weight seeds 1 and 2 and an outlier-statistics family ('realistic' style of oracle/weights.py).
+# * Weight seeds 1 / 2 of the benign family meet the ONE 1e-3 bar like seed 0 does (19 cases at that bar).
+# * The OUTLIER family cannot be held to it by ANY fp16-operand design: rounding nothing but the operands of the 3x3 convolutions to
+#   fp16 -- every other op exact -- already gives 1.07e-3 at 64x64 (oracle/fp16_floor.py; DESIGN.md section 2 has the attribution), and
+#   its error is heavy-tailed: the max re-rolls by +-35 % between two arithmetic variants with the same rms (sdv1_real1_16x16: 7.7e-4 and
+#   1.04e-3 at rms 1.69e-4 / 1.74e-4).  tests/golden/unet_fp16_floor.json holds, per golden, the error of the REFERENCE arithmetic with every
+#   MFMA operand rounded to fp16 once ("fp16-operand floor": what north_star's 'MFMA fp16' gives at best; builder-independent, measured
+#   on the reference by the oracle).  The outlier family is held to that floor: rms <= 1.10 x floor rms (the stable statistic) and
+#   max-abs <= 1.50 x floor max-abs; the log says for each case whether it also meets 1e-3.
+FLOOR_MAX_FACTOR, FLOOR_RMS_FACTOR = 1.50, 1.10
+_floor = None
+
+
+def _bars(case, golden_dir, style):
+    """(max-abs bar, rms bar, 'tol' | 'floor') of a golden case."""
+    global _floor
+    if _floor is None:
+        import json
+        _floor = json.load(open(os.path.join(golden_dir, 'unet_fp16_floor.json')))
+    if style != 'realistic':
+        return TOL, 2.0e-4, 'tol'
+    f = _floor[case]
+    return FLOOR_MAX_FACTOR * f['maxabs'], FLOOR_RMS_FACTOR * f['rms'], 'floor'
 CFGS = {'tiny': TINY, 'small40': SMALL40, 'sdv1': SD_V1}
 _models = {}
 
 
-def _model(cfg_name, wseed):
-    key = (cfg_name, wseed)
+def _style(z):
+    return str(z['style']) if 'style' in z.files else 'uniform'
+
+
+def _model(cfg_name, wseed, style='uniform'):
+    key = (cfg_name, wseed, style)
     if key not in _models:
         _models.clear()
         torch.cuda.empty_cache()
         from stable_diffusion_amd import UNetModelHIP
         cfg = CFGS[cfg_name]
-        sd = make_state_dict(cfg, wseed)
+        sd = make_state_dict(cfg, wseed, style=style)
         kw = cfg.ref_kwargs()
         kw['use_checkpoint'] = True
         m = UNetModelHIP(**kw)
@@ -44,8 +71,14 @@ def _model(cfg_name, wseed):
 
 # *_t1_741: t in {1, 741} (the batch-2 cases only see 981 / 481); *_b6: CFG batch 6 = txt2img's default n_samples 3
 # (scripts/txt2img.py:110-114); tiny_b10: more than 8 rows per call (n_samples 5), chunked by UNetModelHIP.forward
-CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'small40_16x16', 'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64',
-         'sdv1_96x96', 'sdv1_t1_741_16x16', 'sdv1_b6_16x16', 'tiny_b10_8x8']
+# round 6: *_w1_* / *_w2_*: the same architecture and inputs under weight seeds 1 and 2 (rounds 1-5 measured seed 0 only);
+# *_real*: the 'realistic' family of oracle/weights.py (Student-t weights, x8 outlier rows and gammas, context outlier
+# channels at |x| ~ 30, a nearly clean latent at t = 1 next to white noise at t = 981).  Cases are grouped by (weights) so
+# that each 3.4 GB state dict is built once.
+CASES = ['tiny_16x16', 'tiny_8x24', 'tiny_b1_8x8', 'tiny_b10_8x8', 'tiny_real_16x16', 'small40_16x16',
+         'sdv1_8x8', 'sdv1_16x16', 'sdv1_32x32', 'sdv1_64x64', 'sdv1_96x96', 'sdv1_t1_741_16x16', 'sdv1_b6_16x16',
+         'sdv1_w1_16x16', 'sdv1_w1_32x32', 'sdv1_w1_64x64', 'sdv1_w2_16x16', 'sdv1_w2_32x32', 'sdv1_w2_64x64',
+         'sdv1_real_16x16', 'sdv1_real_32x32', 'sdv1_real_64x64', 'sdv1_real1_16x16']
 _measured = {}
 
 
@@ -54,9 +87,9 @@ def test_unet_eps_matches_reference_golden(case, golden_dir):
     z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
     cfg_name = case.split('_')[0]
     cfg = CFGS[cfg_name]
-    m, sd = _model(cfg_name, int(z['weight_seed']))
+    m, sd = _model(cfg_name, int(z['weight_seed']), _style(z))
     x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
-                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']), style=_style(z))
     assert torch.equal(t, torch.from_numpy(z['t']))
     eps = m(x.cuda(), t.cuda(), context=ctx.cuda())
     torch.cuda.synchronize()
@@ -65,9 +98,15 @@ def test_unet_eps_matches_reference_golden(case, golden_dir):
     print(f'[unet {case}] HIP-vs-reference(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e} '
           f'|eps|max {ref.abs().max():.3f} nan={bool(torch.isnan(eps).any())}', flush=True)
     assert eps.shape == ref.shape and eps.dtype == torch.float32
-    _measured[case] = float(err.max())
-    assert float(err.max()) <= TOL
-    assert float(err.pow(2).mean().sqrt()) <= 2.0e-4
+    bar_max, bar_rms, kind = _bars(case, golden_dir, _style(z))
+    if kind == 'floor':
+        f = _floor[case]
+        print(f'[unet {case}] outlier family, held to its fp16-operand floor (floor max-abs {f["maxabs"]:.3e} rms {f["rms"]:.3e}): '
+              f'HIP / floor = {float(err.max()) / f["maxabs"]:.2f} (max) {float(err.pow(2).mean().sqrt()) / f["rms"]:.2f} (rms); '
+              f'meets {TOL:.0e}: {"yes" if float(err.max()) <= TOL else "NO"}', flush=True)
+    _measured[case] = (float(err.max()), kind)
+    assert float(err.max()) <= bar_max
+    assert float(err.pow(2).mean().sqrt()) <= bar_rms
 
 
 def test_parity_headroom_report():
@@ -75,10 +114,11 @@ def test_parity_headroom_report():
     of tile / split-K choices that erodes it is visible in the log before it fails."""
     if not _measured:
         pytest.skip('runs after the golden cases')
-    worst = max(_measured.values())
-    tight = {k: f'{v:.3e}' for k, v in sorted(_measured.items()) if v > HEADROOM_WARN}
-    print(f'[unet headroom] worst {worst:.3e} of {TOL:.0e} ({(1 - worst / TOL) * 100:.0f} % margin); above {HEADROOM_WARN:.1e}: {tight}',
-          flush=True)
+    held = {k: v for k, (v, kind) in _measured.items() if kind == 'tol'}
+    worst = max(held.values())
+    tight = {k: f'{v:.3e}' for k, v in sorted(held.items()) if v > HEADROOM_WARN}
+    print(f'[unet headroom] worst {worst:.3e} of {TOL:.0e} over {len(held)} cases ({(1 - worst / TOL) * 100:.0f} % margin); above {HEADROOM_WARN:.1e}: {tight}; '
+          f'held to their fp16-operand floor instead: { {k: f"{v:.3e}" for k, (v, kind) in sorted(_measured.items()) if kind == "floor"} }', flush=True)
     assert worst <= TOL
 
 
@@ -114,7 +154,7 @@ def test_parity_does_not_depend_on_the_tuning_table():
     errs = {l.split()[1]: float(l.split()[2]) for l in r.stdout.splitlines() if l.startswith('ERR')}
     assert sorted(errs) == sorted(cases), r.stdout[-1000:]
     for case in cases:
-        print(f'[unet {case}, SDMI_TUNE_DISABLE=1] max-abs {errs[case]:.3e} (table: {_measured.get(case, float("nan")):.3e})', flush=True)
+        print(f'[unet {case}, SDMI_TUNE_DISABLE=1] max-abs {errs[case]:.3e} (table: {_measured.get(case, (float("nan"),))[0]:.3e})', flush=True)
     assert max(errs.values()) <= TOL, errs
 
 
@@ -432,13 +472,12 @@ def test_groupnorm_inside_the_splitk_reduction_is_bit_identical(case, golden_dir
     assert torch.equal(e1, e0), float((e1 - e0).abs().max())
 
 
-@pytest.mark.experiments
 @pytest.mark.gpu
 @pytest.mark.parametrize('case', ['sdv1_8x8', 'sdv1_16x16', 'sdv1_64x64', 'sdv1_b6_16x16', 'tiny_16x16'])
 def test_groupnorm_applied_behind_the_reductions_grid_barrier_is_bit_identical(case, golden_dir, monkeypatch):
     """ResBlock conv1 -> GroupNorm + SiLU -> conv2 (openaimodel.py:225-231) where conv1 is split along K: the reduction applies the
-    GroupNorm itself behind a grid barrier (splitk_reduce_tiled_kernel<COOP>; experiments build, SDMI_REDUCE_GN_COOP=1) instead of leaving it to a GroupNorm-apply
-    launch (SDMI_REDUCE_GN_COOP=0).  The same fp32 value, the same statistics words folded by the same function, the same elementwise
+    GroupNorm itself behind a grid barrier (splitk_reduce_tiled_kernel<COOP>, SDMI_REDUCE_GN_XCD=1: the hierarchical barrier of round 6) instead of leaving it to a GroupNorm-apply
+    launch (SDMI_REDUCE_GN_XCD=0).  The same fp32 value, the same statistics words folded by the same function, the same elementwise
     function: eps must not change by one bit, three calls in a row."""
     z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
     cfg_name = case.split('_')[0]
@@ -447,9 +486,9 @@ def test_groupnorm_applied_behind_the_reductions_grid_barrier_is_bit_identical(c
     x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
                             ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']))
     ref = torch.from_numpy(z['eps'])
-    monkeypatch.setenv('SDMI_REDUCE_GN_COOP', '0')
+    monkeypatch.setenv('SDMI_REDUCE_GN_XCD', '0')
     e0 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
-    monkeypatch.setenv('SDMI_REDUCE_GN_COOP', '1')
+    monkeypatch.setenv('SDMI_REDUCE_GN_XCD', '1')
     for rep in range(3):
         e1 = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
         torch.cuda.synchronize()
