@@ -464,6 +464,7 @@ int launch_ln_fold_prep(const f16* w, int N, int K, int ldw, const float* gamma,
                         float* d, hipStream_t s);
 // split-fp16 weights for the 3-pass 1x1 convs: dst [N][3K] = [hi | hi | lo], lo = fp16(w - float(hi))
 int launch_pack_split3(const float* w, f16* dst, int N, int K, hipStream_t s);
+int launch_pack_conv_split3(const float* w, f16* dst, int O, int I, int KH, int KW, hipStream_t s);
 int launch_pack_geglu(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K, hipStream_t s);
 int launch_pack_conv_out(const float* w_oihw, float* dst, int O, int I, hipStream_t s);   // -> [O][3][3][I] fp32
 

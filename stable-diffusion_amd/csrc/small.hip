@@ -298,6 +298,24 @@ __global__ void pack_conv_kernel(const float* w, f16* dst, int O, int I, int KH,
   }
   dst[idx] = (f16)w[(((int64_t)o * I + i) * KH + ky) * KW + kx];
 }
+// 3x3 conv weights of a 3-pass split-fp16 convolution (UNet: the last ResBlock, round 6): the K-concatenated operand A' = [a_hi | a_lo | a_hi]
+// (three channel blocks of I) meets W' = [w_hi | w_hi | w_lo] -- a virtual [O][3 I][KH][KW] tensor in pack_conv_kernel's chunk-major K order
+__global__ void pack_conv_split3_kernel(const float* w, f16* dst, int O, int I, int KH, int KW) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int I3 = 3 * I;
+  const int64_t K = (int64_t)I3 * KH * KW;
+  if (idx >= (int64_t)O * K) return;
+  const int o = (int)(idx / K);
+  const int64_t k = idx - (int64_t)o * K;
+  const int chunk = (int)(k / (64 * KH * KW));
+  const int rem = (int)(k - (int64_t)chunk * 64 * KH * KW);
+  const int tap = rem / 64;
+  const int i3 = chunk * 64 + rem % 64, ky = tap / KW, kx = tap % KW;
+  const int part = i3 / I, i = i3 - part * I;
+  const float v = w[(((int64_t)o * I + i) * KH + ky) * KW + kx];
+  const f16 hi = (f16)v;
+  dst[idx] = part < 2 ? hi : (f16)(v - (float)hi);
+}
 __global__ void pack_conv_f32_kernel(const float* w, float* dst, int O, int I, int KH, int KW) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t total = (int64_t)O * I * KH * KW;
@@ -559,6 +577,13 @@ int launch_prefetch_lines(const void* ptr, int64_t bytes, hipStream_t s) {
   return 0;
 }
 
+int launch_pack_conv_split3(const float* w, f16* dst, int O, int I, int KH, int KW, hipStream_t s) {
+  SDMI_CHECK(I % 64 == 0, "split-fp16 conv pack: input channels % 64");
+  const int64_t total = (int64_t)O * 3 * I * KH * KW;
+  hipLaunchKernelGGL(pack_conv_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, KH, KW);
+  SDMI_HIP_OK(hipGetLastError());
+  return 0;
+}
 int launch_pack_conv_out(const float* w, float* dst, int O, int I, hipStream_t s) {
   const int64_t total = (int64_t)O * I * 9;
   hipLaunchKernelGGL(pack_conv_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, 3, 3);

@@ -47,21 +47,25 @@ int UNet::build(const sdmi_unet_cfg& c) {
 #ifdef SDMI_EXPERIMENTS      // knobs that LOWER the arithmetic or lost their A/B: not read by the product library
   if (const char* e = getenv("SDMI_PRECISE_1X1")) precise_1x1_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_PRECISE_KV")) precise_kv_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_PRECISE_LAST_RES")) precise_last_res_ = atoi(e) != 0;
+  if (const char* e = getenv("SDMI_PRECISE_1X1_MAX_DS")) precise_1x1_max_ds_ = atoi(e);
   if (const char* e = getenv("SDMI_SIDE_STREAM")) side_stream_ = atoi(e) != 0;
 #endif
   if (const char* e = getenv("SDMI_FUSE_GN_STATS")) fuse_gn_stats_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_LN_FOLD")) ln_fold_ = atoi(e) != 0;
   if (const char* e = getenv("SDMI_LN_FOLD_MIN_ROWS")) ln_fold_min_rows_ = atoi(e);
-  const WKind K1 = precise_1x1_ ? W_SPLIT3 : W_CONV;
 
+  int cur_ds = 1;               // downsample factor of the layer being added (ds below; the middle block sits at the deepest one)
   auto add_res = [&](const std::string& p, int cin, int cout) {
     Layer L; L.kind = L_RES; L.prefix = p; L.cin = cin; L.cout = cout;
     L.emb_off = emb_total_; emb_total_ += cout;
+    L.p1x1 = precise_1x1_ && cur_ds < precise_1x1_max_ds_;
     return L;
   };
   auto add_attn = [&](const std::string& p, int ch) {
     Layer L; L.kind = L_ATTN; L.prefix = p; L.cin = ch; L.cout = ch; L.heads = c.num_heads; L.dh = ch / c.num_heads;
     L.attn_index = n_attn_++;
+    L.p1x1 = precise_1x1_ && cur_ds < precise_1x1_max_ds_;
     return L;
   };
 
@@ -76,6 +80,7 @@ int UNet::build(const sdmi_unet_cfg& c) {
     for (int r = 0; r < c.num_res_blocks; ++r) {
       const int n = (int)input_blocks_.size();
       std::vector<Layer> blk;
+      cur_ds = ds;
       blk.push_back(add_res("input_blocks." + std::to_string(n) + ".0", ch, mult * mc));
       ch = mult * mc;
       if (in_list(c.attention_resolutions, c.n_attention_resolutions, ds))
@@ -91,6 +96,7 @@ int UNet::build(const sdmi_unet_cfg& c) {
       ds *= 2;
     }
   }
+  cur_ds = ds;
   middle_.push_back(add_res("middle_block.0", ch, ch));
   middle_.push_back(add_attn("middle_block.1", ch));
   middle_.push_back(add_res("middle_block.2", ch, ch));
@@ -100,6 +106,7 @@ int UNet::build(const sdmi_unet_cfg& c) {
       const int ich = chans.back(); chans.pop_back();
       const int n = (int)output_blocks_.size();
       std::vector<Layer> blk;
+      cur_ds = ds;
       blk.push_back(add_res("output_blocks." + std::to_string(n) + ".0", ch + ich, mc * mult));
       ch = mc * mult;
       if (in_list(c.attention_resolutions, c.n_attention_resolutions, ds))
@@ -113,6 +120,11 @@ int UNet::build(const sdmi_unet_cfg& c) {
       output_blocks_.push_back(blk);
     }
   }
+
+  // the last ResBlock (output_blocks.<last>.0: its two 3x3 convs are the largest single contributors to the eps error)
+  if (precise_last_res_ && !output_blocks_.empty() && output_blocks_.back()[0].kind == L_RES && output_blocks_.back()[0].cin % 64 == 0 &&
+      output_blocks_.back()[0].cout % 64 == 0)
+    output_blocks_.back()[0].precise3 = true;
 
   // ---- expected state_dict entries and where each one is packed to -------------------
   const int64_t TE = te_;
@@ -131,16 +143,16 @@ int UNet::build(const sdmi_unet_cfg& c) {
       case L_RES:
         expect(p + ".in_layers.0.weight", {ci}, W_F32, (void**)&L.f32[0]);
         expect(p + ".in_layers.0.bias", {ci}, W_F32, (void**)&L.f32[1]);
-        expect(p + ".in_layers.2.weight", {co, ci, 3, 3}, W_CONV, (void**)&L.w16[0]);
+        expect(p + ".in_layers.2.weight", {co, ci, 3, 3}, L.precise3 ? W_CONV_SPLIT3 : W_CONV, (void**)&L.w16[0]);
         expect(p + ".in_layers.2.bias", {co}, W_F32, (void**)&L.f32[2]);
         expect(p + ".emb_layers.1.weight", {co, TE}, W_F32_ROWS, (void**)&emb_w_, L.emb_off, te_);
         expect(p + ".emb_layers.1.bias", {co}, W_F32_ROWS, (void**)&emb_b_, L.emb_off, 1);
         expect(p + ".out_layers.0.weight", {co}, W_F32, (void**)&L.f32[3]);
         expect(p + ".out_layers.0.bias", {co}, W_F32, (void**)&L.f32[4]);
-        expect(p + ".out_layers.3.weight", {co, co, 3, 3}, W_CONV, (void**)&L.w16[1]);
+        expect(p + ".out_layers.3.weight", {co, co, 3, 3}, L.precise3 ? W_CONV_SPLIT3 : W_CONV, (void**)&L.w16[1]);
         expect(p + ".out_layers.3.bias", {co}, W_F32, (void**)&L.f32[5]);
         if (ci != co) {
-          expect(p + ".skip_connection.weight", {co, ci, 1, 1}, K1, (void**)&L.w16[2]);
+          expect(p + ".skip_connection.weight", {co, ci, 1, 1}, L.p1x1 ? W_SPLIT3 : W_CONV, (void**)&L.w16[2]);
           expect(p + ".skip_connection.bias", {co}, W_F32, (void**)&L.f32[6]);
         }
         break;
@@ -148,9 +160,9 @@ int UNet::build(const sdmi_unet_cfg& c) {
         const int64_t C = ci, CD = cfg_.context_dim;
         expect(p + ".norm.weight", {C}, W_F32, (void**)&L.f32[0]);
         expect(p + ".norm.bias", {C}, W_F32, (void**)&L.f32[1]);
-        expect(p + ".proj_in.weight", {C, C, 1, 1}, K1, (void**)&L.w16[0]);
+        expect(p + ".proj_in.weight", {C, C, 1, 1}, L.p1x1 ? W_SPLIT3 : W_CONV, (void**)&L.w16[0]);
         expect(p + ".proj_in.bias", {C}, W_F32, (void**)&L.f32[2]);
-        expect(p + ".proj_out.weight", {C, C, 1, 1}, K1, (void**)&L.w16[1]);
+        expect(p + ".proj_out.weight", {C, C, 1, 1}, L.p1x1 ? W_SPLIT3 : W_CONV, (void**)&L.w16[1]);
         expect(p + ".proj_out.bias", {C}, W_F32, (void**)&L.f32[3]);
         L.tb.resize(cfg_.transformer_depth);
         for (int d = 0; d < cfg_.transformer_depth; ++d) {
@@ -261,7 +273,7 @@ size_t UNet::slot_bytes(const WeightSlot& s) const {
     case W_F32: case W_CONV_OUT: case W_GEGLU_B: return numel * sizeof(float);
     case W_F32_ROWS: return (size_t)emb_total_ * s.ld * sizeof(float);
     case W_CONV: case W_GEGLU_W: return numel * sizeof(f16);
-    case W_SPLIT3: return 3 * numel * sizeof(f16);
+    case W_SPLIT3: case W_CONV_SPLIT3: return 3 * numel * sizeof(f16);
     case W_SPLIT3_ROWS: return 2 * 3 * numel * sizeof(f16);      // (to_k | to_v share one [2C][3 K] buffer)
     case W_ROWS16: {
       size_t total_rows = (size_t)s.shape[0];
@@ -306,6 +318,10 @@ int UNet::set_weight(const char* key, const float* ptr, const int64_t* shape, in
     case W_SPLIT3:
       rc = dev_alloc(s.dst, slot_bytes(s));
       if (!rc) rc = launch_pack_split3(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], stream);
+      break;
+    case W_CONV_SPLIT3:
+      rc = dev_alloc(s.dst, slot_bytes(s));
+      if (!rc) rc = launch_pack_conv_split3(dptr, (f16*)*s.dst, (int)shape[0], (int)shape[1], (int)shape[2], (int)shape[3], stream);
       break;
     case W_SPLIT3_ROWS:  // rows [row0, row0 + rows) of a split-fp16 [*][3 ld] matrix
       rc = dev_alloc(s.dst, slot_bytes(s));
@@ -429,7 +445,7 @@ int UNet::export_packed(void* host_buf, int64_t bytes, hipStream_t stream) {
   PackedHeader h{};
   memcpy(h.magic, "SDMIPK01", 8);
   h.abi = SDMI_ABI_VERSION; h.precise_1x1 = precise_1x1_ ? 1 : 0; h.n_buffers = (int32_t)bufs.size(); h.cfg = cfg_;
-  h.reserved = precise_kv_ ? 1 : 0;      // (ABI 17: split-fp16 context K / V weights)
+  h.reserved = (precise_kv_ ? 1 : 0) | (precise_last_res_ ? 2 : 0) | (precise_1x1_max_ds_ << 8);      // (ABI 17: the precision allocation)
   h.total_bytes = total;
   memcpy(host_buf, &h, sizeof(h));
   int64_t off = (int64_t)round_up((int64_t)sizeof(PackedHeader), PK_ALIGN);
@@ -449,7 +465,8 @@ int UNet::import_packed(const void* host_buf, int64_t bytes, hipStream_t stream)
   SDMI_CHECK(h.abi == SDMI_ABI_VERSION, "packed blob was written by a different ABI version: repack it");
   SDMI_CHECK(memcmp(&h.cfg, &cfg_, sizeof(cfg_)) == 0, "packed blob was written for a different UNet configuration");
   SDMI_CHECK((h.precise_1x1 != 0) == precise_1x1_, "packed blob was written with a different SDMI_PRECISE_1X1 setting");
-  SDMI_CHECK((h.reserved != 0) == precise_kv_, "packed blob was written with a different SDMI_PRECISE_KV setting");
+  SDMI_CHECK(h.reserved == ((precise_kv_ ? 1 : 0) | (precise_last_res_ ? 2 : 0) | (precise_1x1_max_ds_ << 8)),
+             "packed blob was written with a different precision allocation (SDMI_PRECISE_KV / _LAST_RES / _1X1_MAX_DS)");
   std::vector<std::pair<void**, size_t>> bufs;
   int64_t total = 0;
   packed_layout(&bufs, &total);
@@ -523,18 +540,23 @@ struct Fwd : FwdBase {
     constexpr int fold_which = 3, fold_w = 0;     // (gn_fold_conv_supported() is false in the product build: no fold site)
 #endif
     const bool fold_here = fold_w == 0 || fold_w == W;
-    const bool fold1 = (fold_which & 1) && fold_here && gn_fold_conv_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
-    const bool fold2 = (fold_which & 2) && fold_here && gn_fold_conv_supported(B, H, W, Cout, 0, Cout);
+    const bool fold1 = !L.precise3 && (fold_which & 1) && fold_here && gn_fold_conv_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
+    const bool fold2 = !L.precise3 && (fold_which & 2) && fold_here && gn_fold_conv_supported(B, H, W, Cout, 0, Cout);
     f16* raw = (Cin != Cout) ? S<f16>((size_t)M * Cin) : nullptr;
-    f16* raw_lo = (Cin != Cout && precise_1x1) ? S<f16>((size_t)M * Cin) : nullptr;
+    const bool p1 = L.p1x1;              // this layer's skip convolution as 3-pass split-fp16
+    const bool p3 = L.precise3;          // ... and its two 3x3 convs (the last ResBlock): operands [hi | lo | hi] against packed [w_hi | w_hi | w_lo]
+    f16* raw_lo = (Cin != Cout && p1) ? S<f16>((size_t)M * Cin) : nullptr;
+    auto split3 = [&](IGemmParams& q, const f16* hi, const f16* lo, int C) {
+      q.a0 = hi; q.c0 = C; q.lda0 = C; q.a1 = lo; q.c1 = C; q.lda1 = C; q.a2 = hi; q.c2 = C; q.lda2 = C; q.K = 27 * C; q.k_alg = 9 * C;
+    };
     float* h = S<float>((size_t)M * Cout);
     Act out = make_act(P<float>((size_t)M * Cout), Cout, H, W, true);
     Act hact = make_act(h, Cout, H, W, true);
     f16* a2 = nullptr; int gn2_applied = 0;
     // in_layers / out_layers as ONE launch each (gnconv.hip: 32 pixels x all 320 output channels per workgroup, the halo normalised once):
     // the 64 x 64 level of SD v1.  (in_layers only without a skip convolution: that one reads raw fp16 copies the GroupNorm launch writes.)
-    const bool gc1 = gn_conv_on && !fold1 && Cin == Cout && gn_conv3_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
-    const bool gc2 = gn_conv_on && !fold2 && gn_conv3_supported(B, H, W, Cout, 0, Cout);
+    const bool gc1 = gn_conv_on && !L.precise3 && !fold1 && Cin == Cout && gn_conv3_supported(B, H, W, x0.C, x1 ? x1->C : 0, Cout);
+    const bool gc2 = gn_conv_on && !L.precise3 && !fold2 && gn_conv3_supported(B, H, W, Cout, 0, Cout);
     auto gn_conv = [&](const Act& a0, const Act* a1, const float* gamma, const float* beta, const f16* w, IGemmParams& e) {
       GnConvParams g;
       g.gn_acc = groupnorm(a0, a1, gamma, beta, 1e-5f, 1, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
@@ -554,14 +576,16 @@ struct Fwd : FwdBase {
         p = conv3_gn(x0, x1, L.f32[0], L.f32[1], L.w16[0], Cout, raw, raw_lo);    // (+ the skip conv's raw hi | lo operand)
       } else {
         f16* a = S<f16>((size_t)M * Cin);
-        groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, nullptr, raw_lo);
+        f16* a_lo = p3 ? S<f16>((size_t)M * Cin) : nullptr;
+        groupnorm(x0, x1, L.f32[0], L.f32[1], 1e-5f, 1, a, nullptr, raw, a_lo, raw_lo);
         p = conv3(a, Cin, H, W, H, W, 1, 0, L.w16[0], Cout);
+        if (p3) split3(p, a, a_lo, Cin);
       }
       if (Cin != Cout && !fold1) fork_side();
       p.bias = L.f32[2]; p.rowvec = emb_all + L.emb_off; p.ld_rowvec = emb_ld;
       p.out_f32 = h; p.ldo = Cout;
       attach_gn_targets(p, hact);          // statistics of out_layers' GroupNorm come out of this epilogue
-      if (!fold2 && !gc2) {
+      if (!fold2 && !gc2 && !p3) {
         // ... or, where this conv ends up split along K (8x8, 16x16, the concat blocks of 32x32), GroupNorm + SiLU are applied by
         // its split-K reduction: a2 = the conv2 operand comes straight out of it (IGemmParams::pgn_*; gn2_applied says so)
         a2 = S<f16>((size_t)M * Cout);
@@ -571,7 +595,7 @@ struct Fwd : FwdBase {
     }
     const float* residual = x0.p;
     if (Cin != Cout) {       // skip_connection: needs only the raw fp16 copies (written by GroupNorm 1 / by conv1's staging)
-      IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W);
+      IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W, p1);
       p.bias = L.f32[6]; p.out_f32 = out.p; p.ldo = Cout;
       if (fold1) gemm(p); else gemm_side(p);
       residual = out.p;
@@ -588,8 +612,11 @@ struct Fwd : FwdBase {
       if (fold2) {
         p = conv3_gn(hact, nullptr, L.f32[3], L.f32[4], L.w16[1], Cout, nullptr, nullptr);
       } else {
-        groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr, nullptr, nullptr, false, gn2_applied != 0);
+        f16* a2_lo = nullptr;
+        if (p3) { a2 = S<f16>((size_t)M * Cout); a2_lo = S<f16>((size_t)M * Cout); }
+        groupnorm(hact, nullptr, L.f32[3], L.f32[4], 1e-5f, 1, a2, nullptr, nullptr, a2_lo, nullptr, false, gn2_applied != 0);
         p = conv3(a2, Cout, H, W, H, W, 1, 0, L.w16[1], Cout);
+        if (p3) split3(p, a2, a2_lo, Cout);
       }
       if (Cin != Cout && !fold1) join_side();
       p.bias = L.f32[5]; p.residual = residual; p.ldr = Cout; p.out_f32 = out.p; p.ldo = Cout;
@@ -625,17 +652,18 @@ struct Fwd : FwdBase {
     const float scale = 1.0f / sqrtf((float)L.dh);
     const size_t mark = scratch.off;
     f16* xn = S<f16>((size_t)M * C);
-    f16* xn_lo = precise_1x1 ? S<f16>((size_t)M * C) : nullptr;
+    const bool p1 = L.p1x1;              // proj_in / proj_out of this SpatialTransformer as 3-pass split-fp16
+    f16* xn_lo = p1 ? S<f16>((size_t)M * C) : nullptr;
     // proj_in(norm(x)), attention.py:254-255: the GroupNorm either as its own launch (fp32 stream -> split-fp16 hi | lo operands) or
     // applied inside the GEMM while it stages its A operand (gemm_split16_gn_kernel: same operand bits, same products, one launch less)
     IGemmParams pin;
     pin.M = M; pin.N = C; pin.K = C; pin.ksize = 1; pin.Hout = N; pin.Wout = 1; pin.B = B;
     const bool fold_ln = ln_fold_on && C % 64 == 0 && C <= 1280 && N % 64 == 0 && M % 64 == 0 && M >= u->ln_fold_min_rows_;
-    const bool gn_in_gemm = gn_proj_fold && fold_ln && precise_1x1 && M >= 512 && split16_gn_supported(pin);
+    const bool gn_in_gemm = gn_proj_fold && fold_ln && p1 && M >= 512 && split16_gn_supported(pin);
     // the head of the SpatialTransformer (GroupNorm-apply -> proj_in -> q | k | v of the first transformer block) as one row-strip chain
     // launch (rowchain.hip st_head_kernel; UNet::st_head_): LayerNorm fold on, split-fp16 proj_in, C = 320
-    const bool chain_head = st_head_on && fold_ln && precise_1x1 && !gn_in_gemm && L.tb[0].lnf[0] != nullptr &&
-                            st_head_supported(C, M, N, Np, L.heads, L.dh) && dense1x1(nullptr, nullptr, M, C, L.w16[0], C, N).split16;
+    const bool chain_head = st_head_on && fold_ln && p1 && !gn_in_gemm && L.tb[0].lnf[0] != nullptr &&
+                            st_head_supported(C, M, N, Np, L.heads, L.dh) && dense1x1(nullptr, nullptr, M, C, L.w16[0], C, N, p1).split16;
     long long* gn_stats = nullptr;
     if (gn_in_gemm || chain_head) gn_stats = groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, nullptr, nullptr, nullptr, nullptr, nullptr, /*stats_only=*/true);
     else groupnorm(x, nullptr, L.f32[0], L.f32[1], 1e-6f, 0, xn, nullptr, nullptr, xn_lo, nullptr);
@@ -680,7 +708,7 @@ struct Fwd : FwdBase {
       if (p.ln_out) ok(fail("internal: GroupNorm-folding proj_in needs the LayerNorm fold"));
       if (!dry && !rc) ok(launch_split16_gn(p, s));
     } else {
-      IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N);
+      IGemmParams p = dense1x1(xn, xn_lo, M, C, L.w16[0], C, N, p1);
       p.bias = L.f32[2]; p.out_f32 = t; p.ldo = C;
       with_ln(p, L.tb[0].ln[0], L.tb[0].ln[1]);                      // norm1 of the first block
       gemm(p);
@@ -688,8 +716,8 @@ struct Fwd : FwdBase {
     const int depth = (int)L.tb.size();
     // the tail of the SpatialTransformer (GEGLU -> FF-out -> proj_out) as one row-strip chain launch: last (= only) transformer block,
     // LayerNorm fold on, split-fp16 proj_out, C = 320 (UNet::ff_tail_)
-    const bool chain_ff = ff_tail_on && fold_ln && precise_1x1 && depth == 1 && L.tb[0].lnf_csd != nullptr && ff_tail_supported(C, M, N) &&
-                          dense1x1(nullptr, nullptr, M, C, L.w16[1], C, N).split16;
+    const bool chain_ff = ff_tail_on && fold_ln && p1 && depth == 1 && L.tb[0].lnf_csd != nullptr && ff_tail_supported(C, M, N) &&
+                          dense1x1(nullptr, nullptr, M, C, L.w16[1], C, N, p1).split16;
     const bool chain_tail = chain_ff && st_tail_on;      // ... with attn2's out-projection in front (ff_tail_kernel HEAD)
     for (int d = 0; d < depth; ++d) {
       TBlock& T = L.tb[d];
@@ -775,7 +803,7 @@ struct Fwd : FwdBase {
     }
     Act out = make_act(P<float>((size_t)M * C), C, H, W, true);
     {
-      IGemmParams p = dense1x1(ln, xn_lo, M, C, L.w16[1], C, N);
+      IGemmParams p = dense1x1(ln, xn_lo, M, C, L.w16[1], C, N, p1);
       p.Hout = H * W;                       // (dense: rows per sample)
       p.bias = L.f32[3]; p.residual = x.p; p.ldr = C; p.out_f32 = out.p; p.ldo = C;
       attach_gn_targets(p, out);

@@ -176,9 +176,9 @@ struct FwdBase {
   // 1x1 conv on split-fp16 operands (packed W_SPLIT3 weights [N][3K] = [hi | hi | lo]) when precise: the split-fp16 GEMM family
   // (gemm_split16.hip: four operand tiles per 64-channel chunk, three MFMAs per fragment pair); SDMI_SPLIT16_KERNEL=0 = the
   // rounds-1/2 formulation, one K-concatenated GEMM A' = [hi | lo | hi] through the generic kernel (A/B)
-  IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch) {
+  IGemmParams dense1x1(const f16* hi, const f16* lo, int M, int K, const f16* w, int N, int rows_per_batch, bool precise) {
     IGemmParams p = dense(hi, M, K, w, N, rows_per_batch);
-    if (precise_1x1) {
+    if (precise) {
       static const bool family = !(getenv("SDMI_SPLIT16_KERNEL") && atoi(getenv("SDMI_SPLIT16_KERNEL")) == 0);
       if (family && K % 64 == 0) {
         p.a1 = lo; p.lda1 = K; p.split16 = 1; p.ldw = 3 * K;
@@ -232,7 +232,7 @@ struct DevStage {
 };
 
 enum LayerKind { L_CONV_IN, L_RES, L_ATTN, L_DOWN, L_UP };
-enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B, W_SPLIT3, W_SPLIT3_ROWS };
+enum WKind { W_F32, W_F32_ROWS, W_CONV, W_CONV_OUT, W_ROWS16, W_GEGLU_W, W_GEGLU_B, W_SPLIT3, W_SPLIT3_ROWS, W_CONV_SPLIT3 };
 
 struct TBlock {   // BasicTransformerBlock (ldm/modules/attention.py:196-215)
   f16* wqkv = nullptr;   // [3C][C]   attn1 to_q | to_k | to_v
@@ -256,6 +256,12 @@ struct Layer {
   LayerKind kind = L_RES;
   std::string prefix;
   int cin = 0, cout = 0, heads = 0, dh = 0, emb_off = 0, attn_index = -1;
+  // Precision allocation by measured sensitivity (round 6; DESIGN.md section 2, oracle/fp16_floor.py):
+  //   p1x1     the layer's 1x1 convs on the residual stream (skip_connection / proj_in / proj_out) as 3-pass split-fp16 -- the two upper levels
+  //            (downsample factors 1 and 2): single-pass fp16 there would add 87 % / 15 % to the eps error variance, at downsample factor 4
+  //            3.5 %, at 8 and in the middle block 0.1 % -- those run single-pass (-0.08 ms per UNet call);
+  //   precise3 the ResBlock's two 3x3 convs as 3-pass split-fp16 -- the LAST ResBlock only, which alone carries 26 - 30 % of that variance
+  bool p1x1 = true, precise3 = false;
   f16* w16[3] = {nullptr, nullptr, nullptr};
   float* w32[1] = {nullptr};
   float* f32[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -303,6 +309,8 @@ class UNet {
   // 1x1 convs on the residual stream (skip_connection, proj_in, proj_out) run as 3-pass split-fp16 GEMMs
   // (a_hi*w_hi + a_lo*w_hi + a_hi*w_lo): ~22-bit operands for 5 % of the FLOPs (DESIGN.md "precision")
   bool precise_1x1_ = true;
+  bool precise_last_res_ = true;   // the last ResBlock's 3x3 convs as 3-pass split-fp16 (round 6; Layer::precise3)
+  int precise_1x1_max_ds_ = 4;     // stream 1x1 convs are split-fp16 at downsample factors below this (round 6; Layer::p1x1)
   bool precise_kv_ = true;     // context K / V projections as 3-pass split-fp16 (round 6; see UNet::build)
   // ResBlock convs fold the GroupNorm + SiLU of their input into their halo staging (conv3halo.hip, conv3halo_gn_kernel) wherever
   // gn_fold_conv_supported() says so; SDMI_FUSE_GN_CONV=0 restores the GroupNorm-apply launches (A/B).

@@ -223,7 +223,7 @@ struct VFwd : FwdBase {
     }
     const float* residual = x.p;
     if (nin) {
-      IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W);
+      IGemmParams p = dense1x1(raw, raw_lo, M, Cin, L.w16[2], Cout, H * W, precise_1x1);
       p.bias = L.f32[6]; p.out_f32 = out.p; p.ldo = Cout;
       gemm(p);
       residual = out.p;
