@@ -143,14 +143,23 @@ def unet_latency_ms(unet, device, H=64, W=64, iters=10):
     unet.pin_context(ctx)
     for _ in range(2):
         unet(x, t, context=ctx)
+    # host time to ENQUEUE one call, from an idle stream (round 6: the figure of rounds 1-5 was taken inside the 10-call loop below,
+    # where the host blocks in hipLaunchKernel on a full queue -- it measured the device, 3.6 ms, not the executor: tools/host_enqueue.py)
+    enq = []
+    for _ in range(7):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        unet(x, t, context=ctx)
+        enq.append(time.perf_counter() - t0)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(iters):
         unet(x, t, context=ctx)
-    t_host = time.perf_counter() - t0          # the host is done ENQUEUEING here; if this is the whole time, the call is host-bound
+    t_host = time.perf_counter() - t0          # (with queue back-pressure: ~ the device time once the queue is full)
     torch.cuda.synchronize()
     unet.unpin_context()
-    unet_latency_ms.host_enqueue_ms = t_host / iters * 1e3
+    unet_latency_ms.host_enqueue_ms = sorted(enq)[len(enq) // 2] * 1e3
+    unet_latency_ms.host_loop_ms = t_host / iters * 1e3
     return (time.perf_counter() - t0) / iters * 1e3
 
 
@@ -565,7 +574,8 @@ def main():
             out['box_probe'] = box_probe(device)
             ms = unet_latency_ms(unet, device, H=LAT, W=LAT)
             out['unet_ms_per_call'] = ms
-            out['unet_host_enqueue_ms_per_call'] = round(getattr(unet_latency_ms, 'host_enqueue_ms', float('nan')), 3)   # host time to enqueue one call
+            out['unet_host_enqueue_ms_per_call'] = round(getattr(unet_latency_ms, 'host_enqueue_ms', float('nan')), 3)   # host time to enqueue one call from an idle stream (launch tapes, csrc/tape.h)
+            out['unet_host_loop_ms_per_call'] = round(getattr(unet_latency_ms, 'host_loop_ms', float('nan')), 3)       # ... inside a back-to-back loop: queue back-pressure included (the round 1-5 figure)
             out['unet_calls_per_image'] = wl['calls']
             out['unet_tflops'] = UNET_GFLOP[LAT] / ms
             out['vae_decode_ms'] = vae_latency_ms(vae, device, H=LAT)

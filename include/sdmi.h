@@ -93,6 +93,12 @@ int sdmi_unet_reserve_context(sdmi_unet* h, int B, int Lctx);
  * consumed by that one call.  t_host: host memory.  Setting weights drops the table. */
 int sdmi_unet_cache_timesteps(sdmi_unet* h, const int64_t* t_host, int n, void* stream);
 int sdmi_unet_hint_timestep(sdmi_unet* h, int64_t t);
+/* Launch tapes (ABI 17; csrc/tape.h): sdmi_unet_forward records the launch list of a (B, H, W, Lctx, workspace, timestep mode, knobs) once and
+ * replays it -- no dry pass, no table lookups, no descriptor fills -- patching only the caller's pointers (x, eps_out, timesteps, context, the
+ * timestep-table row).  There is nothing to call: this reports how many forwards were replayed / recorded (tests, bench.py).  SDMI_REPLAY=0
+ * turns the tapes off; SDMI_REPLAY_VERIFY=1 runs the executor on every would-be replay and fails if the patched tape differs from it.
+ * No counterpart in the reference (pure Python, scripts/txt2img.py drives torch ops one by one). */
+int sdmi_unet_tape_stats(sdmi_unet* h, int64_t* replayed, int64_t* recorded);
 
 /* UNetModel.forward(x, timesteps, context) openaimodel.py:710-742, reached through
  * LatentDiffusion.apply_model ddpm.py:891-900,986-992 and DiffusionWrapper.forward ddpm.py:1402-1410.

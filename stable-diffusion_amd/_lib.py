@@ -67,6 +67,7 @@ _SIGS = {
     'sdmi_unet_reserve_context': (C.c_int, [c_ptr, C.c_int, C.c_int]),
     'sdmi_unet_cache_timesteps': (C.c_int, [c_ptr, C.POINTER(C.c_int64), C.c_int, c_ptr]),
     'sdmi_unet_hint_timestep': (C.c_int, [c_ptr, C.c_int64]),
+    'sdmi_unet_tape_stats': (C.c_int, [c_ptr, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     'sdmi_unet_forward': (C.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, C.c_int, C.c_int, C.c_int, C.c_int,
                                     c_ptr, C.c_int64, c_ptr]),
     'sdmi_sampler_step': (C.c_int, [c_ptr, C.c_int, C.c_float, c_ptr, C.c_int, c_ptr, c_ptr, c_ptr, C.c_float,

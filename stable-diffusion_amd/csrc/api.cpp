@@ -112,6 +112,12 @@ int sdmi_unet_hint_timestep(sdmi_unet* h, int64_t t) {
   SDMI_CHECK(h, "null argument");
   return h->impl.hint_timestep(t);
 }
+int sdmi_unet_tape_stats(sdmi_unet* h, int64_t* replayed, int64_t* recorded) {
+  SDMI_CHECK(h, "null argument");
+  if (replayed) *replayed = (int64_t)h->impl.tape_hits_;
+  if (recorded) *recorded = (int64_t)h->impl.tape_records_;
+  return 0;
+}
 int sdmi_unet_forward(sdmi_unet* h, const float* x, const int64_t* t_i64, const float* t_f32, const float* ctx,
                       float* eps_out, int B, int H, int W, int Lctx, void* workspace, int64_t workspace_bytes, void* stream) {
   SDMI_CHECK(h && x && eps_out, "null argument");

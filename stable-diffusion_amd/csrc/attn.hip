@@ -806,28 +806,28 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
 #ifdef SDMI_ABLATE
       if constexpr (D == 40) {
         switch (abl) {
-          case 1: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 1>), grid, dim3(512), 0, stream, p); break;
-          case 2: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 2>), grid, dim3(512), 0, stream, p); break;
-          case 3: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 3>), grid, dim3(512), 0, stream, p); break;
-          case 4: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 4>), grid, dim3(512), 0, stream, p); break;
-          case 5: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 5>), grid, dim3(512), 0, stream, p); break;
-          default: hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false, 6>), grid, dim3(512), 0, stream, p); break;
+          case 1: SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 1>), grid, dim3(512), 0, stream, p); break;
+          case 2: SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 2>), grid, dim3(512), 0, stream, p); break;
+          case 3: SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 3>), grid, dim3(512), 0, stream, p); break;
+          case 4: SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 4>), grid, dim3(512), 0, stream, p); break;
+          case 5: SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 5>), grid, dim3(512), 0, stream, p); break;
+          default: SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 6>), grid, dim3(512), 0, stream, p); break;
         }
       }
 #endif
 #ifdef SDMI_EXPERIMENTS
     } else if (nw == 8 && p.pingpong && DNS >= 4) {
-      if constexpr (DNS >= 4) hipLaunchKernelGGL((attn_pp_kernel<D, DNS>), grid, dim3(512), 0, stream, p);
+      if constexpr (DNS >= 4) SDMI_LAUNCH((attn_pp_kernel<D, DNS>), grid, dim3(512), 0, stream, p);
 #endif
-    } else if (nw == 8) hipLaunchKernelGGL((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
-    else if (nw == 4) hipLaunchKernelGGL((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
-    else hipLaunchKernelGGL((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);
+    } else if (nw == 8) SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
+    else if (nw == 4) SDMI_LAUNCH((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
+    else SDMI_LAUNCH((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);
   } else if (p.causal) {          // the text encoder's 77-token self-attention: one configuration is enough
-    if constexpr (D == 32 || D == 64 || D == 128) hipLaunchKernelGGL((attn_kernel<D, 2, true>), dim3(cdiv(p.nq, 64), p.BH), dim3(128), 0, stream, p);
+    if constexpr (D == 32 || D == 64 || D == 128) SDMI_LAUNCH((attn_kernel<D, 2, true>), dim3(cdiv(p.nq, 64), p.BH), dim3(128), 0, stream, p);
     else return fail("causal attention is instantiated for head dims 32 / 64 / 128");
-  } else if (nw == 8) hipLaunchKernelGGL((attn_kernel<D, 8, false>), grid, dim3(512), 0, stream, p);
-  else if (nw == 4) hipLaunchKernelGGL((attn_kernel<D, 4, false>), grid, dim3(256), 0, stream, p);
-  else hipLaunchKernelGGL((attn_kernel<D, 2, false>), grid, dim3(128), 0, stream, p);
+  } else if (nw == 8) SDMI_LAUNCH((attn_kernel<D, 8, false>), grid, dim3(512), 0, stream, p);
+  else if (nw == 4) SDMI_LAUNCH((attn_kernel<D, 4, false>), grid, dim3(256), 0, stream, p);
+  else SDMI_LAUNCH((attn_kernel<D, 2, false>), grid, dim3(128), 0, stream, p);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -300,9 +300,9 @@ int launch_ctx_d(const AttnCtxParams& p, hipStream_t stream) {
   static const int env_nw = env_int("SDMI_ATTN_CTX_NW", 0);       // A/B knob
   int nw = (long)cdiv(p.nq, 128) * p.BH >= 256 ? 4 : ((long)cdiv(p.nq, 64) * p.BH >= 128 ? 2 : 1);
   if (env_nw == 1 || env_nw == 2 || env_nw == 4) nw = env_nw;
-  if (nw == 4) hipLaunchKernelGGL((attn_ctx_kernel<D, 4>), dim3(cdiv(p.nq, 128), p.BH), dim3(256), 0, stream, p);
-  else if (nw == 2) hipLaunchKernelGGL((attn_ctx_kernel<D, 2>), dim3(cdiv(p.nq, 64), p.BH), dim3(128), 0, stream, p);
-  else hipLaunchKernelGGL((attn_ctx_kernel<D, 1>), dim3(cdiv(p.nq, 32), p.BH), dim3(64), 0, stream, p);
+  if (nw == 4) SDMI_LAUNCH((attn_ctx_kernel<D, 4>), dim3(cdiv(p.nq, 128), p.BH), dim3(256), 0, stream, p);
+  else if (nw == 2) SDMI_LAUNCH((attn_ctx_kernel<D, 2>), dim3(cdiv(p.nq, 64), p.BH), dim3(128), 0, stream, p);
+  else SDMI_LAUNCH((attn_ctx_kernel<D, 1>), dim3(cdiv(p.nq, 32), p.BH), dim3(64), 0, stream, p);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   return 0;

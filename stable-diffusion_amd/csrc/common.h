@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <string>
 
+#include "tape.h"
+
 typedef _Float16 f16;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
@@ -266,6 +268,8 @@ int launch_split16_gn(const IGemmParams& p, hipStream_t stream);
 bool gn_fold_conv_supported(int B, int H, int W, int c0, int c1, int N);
 // fp16 range guard (range.hip, debug): scan an fp16 activation buffer a launch just wrote; see SDMI_CHECK_RANGE
 bool range_check_enabled();
+uint64_t tune_generation();
+bool tune_collecting();                 // a tuning collection is running (igemm.hip): launches must go through the executor
 int range_check_set(int enable);
 int range_scan(const char* what, const f16* p, int64_t n, hipStream_t stream);
 int range_report(std::string* json);

@@ -762,7 +762,7 @@ int launch_halo_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
                src_pix * (p.c0 + p.c1) * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_f16 ? 2.0 : 0.0)) +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream);
-  hipLaunchKernelGGL((conv3halo_kernel<BM, BN, WARPS_M, WARPS_N, NS>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
+  SDMI_LAUNCH((conv3halo_kernel<BM, BN, WARPS_M, WARPS_N, NS>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   if (nsplit > 1 && !q.splitk_fused) return launch_splitk_reduce(q, nsplit, stream);
@@ -834,8 +834,8 @@ int launch_halo_gn_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
                src_pix * (p.c0 + p.c1) * 4.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_f16 ? 2.0 : 0.0)) +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream);
-  if (p.raw_hi) hipLaunchKernelGGL((conv3halo_gn_kernel<BM, BN, WARPS_M, WARPS_N, NS, true>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
-  else hipLaunchKernelGGL((conv3halo_gn_kernel<BM, BN, WARPS_M, WARPS_N, NS, false>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
+  if (p.raw_hi) SDMI_LAUNCH((conv3halo_gn_kernel<BM, BN, WARPS_M, WARPS_N, NS, true>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
+  else SDMI_LAUNCH((conv3halo_gn_kernel<BM, BN, WARPS_M, WARPS_N, NS, false>), grid, block, 0, stream, q, tiles_m, tiles_n, chunks_per_split);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   if (nsplit > 1 && !q.splitk_fused) return launch_splitk_reduce(q, nsplit, stream);

@@ -350,7 +350,7 @@ int launch_split16_cfg(const IGemmParams& p, int splitk, hipStream_t stream) {
                (double)p.M * p.K * 2.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_f16 ? 2.0 : 0.0)) +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream, 6.0 * p.M * (double)p.N * p.K);
-  hipLaunchKernelGGL((gemm_split16_kernel<BM, BN, WARPS_M, WARPS_N, NS>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+  SDMI_LAUNCH((gemm_split16_kernel<BM, BN, WARPS_M, WARPS_N, NS>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   if (nsplit > 1 && !q.splitk_fused) return launch_splitk_reduce(q, nsplit, stream);
@@ -398,7 +398,7 @@ int launch_split16_gn(const IGemmParams& p, hipStream_t stream) {
                (double)p.M * p.K * 4.0 + (double)p.N * p.K * 2.0 + (double)p.M * p.N * ((p.out_f32 ? 4.0 : 0.0) + (p.out_f16 ? 2.0 : 0.0)) +
                    (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream, 6.0 * p.M * (double)p.N * p.K);
-  hipLaunchKernelGGL((gemm_split16_gn_kernel<0>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, q, tiles_m, tiles_n);
+  SDMI_LAUNCH((gemm_split16_gn_kernel<0>), dim3(tiles_m * tiles_n), dim3(256), 0, stream, q, tiles_m, tiles_n);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   return 0;

@@ -356,11 +356,11 @@ int launch_gn_conv3(const GnConvParams& p, hipStream_t stream) {
   // ring depth and the prefetch wave (read per launch: A/B)
   const int ns = env_int("SDMI_GN_CONV_NS", 4), pf = env_int("SDMI_GN_CONV_PF", 1);
   if (ns == 6) {
-    if (pf) hipLaunchKernelGGL((gn_conv3_kernel<2, 6, true>), grid, dim3(GC_NTC + 192), 0, stream, q);
-    else hipLaunchKernelGGL((gn_conv3_kernel<2, 6, false>), grid, dim3(GC_NTC + 128), 0, stream, q);
+    if (pf) SDMI_LAUNCH((gn_conv3_kernel<2, 6, true>), grid, dim3(GC_NTC + 192), 0, stream, q);
+    else SDMI_LAUNCH((gn_conv3_kernel<2, 6, false>), grid, dim3(GC_NTC + 128), 0, stream, q);
   } else {
-    if (pf) hipLaunchKernelGGL((gn_conv3_kernel<2, 4, true>), grid, dim3(GC_NTC + 192), 0, stream, q);
-    else hipLaunchKernelGGL((gn_conv3_kernel<2, 4, false>), grid, dim3(GC_NTC + 128), 0, stream, q);
+    if (pf) SDMI_LAUNCH((gn_conv3_kernel<2, 4, true>), grid, dim3(GC_NTC + 192), 0, stream, q);
+    else SDMI_LAUNCH((gn_conv3_kernel<2, 4, false>), grid, dim3(GC_NTC + 128), 0, stream, q);
   }
   SDMI_HIP_OK(hipGetLastError());
   return 0;

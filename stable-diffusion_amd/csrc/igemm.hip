@@ -517,13 +517,13 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     ProfScope psg("splitk_reduce_gn", 0.0, mn * 4.0 * nsplit + mn * 2.0 + (p.residual ? mn * 4.0 : 0.0) + (p.pgn_keep_f32 ? mn * 4.0 : 0.0), stream);
     const dim3 grid(32, (unsigned)p.B), block(1024);
     if (p.slab_tiled) {
-      if (maxq == 1) hipLaunchKernelGGL((splitk_reduce_gn_kernel<1, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
-      else if (maxq == 3) hipLaunchKernelGGL((splitk_reduce_gn_kernel<3, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
-      else hipLaunchKernelGGL((splitk_reduce_gn_kernel<5, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      if (maxq == 1) SDMI_LAUNCH((splitk_reduce_gn_kernel<1, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else if (maxq == 3) SDMI_LAUNCH((splitk_reduce_gn_kernel<3, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else SDMI_LAUNCH((splitk_reduce_gn_kernel<5, true>), grid, block, 0, stream, p, nsplit, magic_qpr);
     } else {
-      if (maxq == 1) hipLaunchKernelGGL((splitk_reduce_gn_kernel<1, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
-      else if (maxq == 3) hipLaunchKernelGGL((splitk_reduce_gn_kernel<3, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
-      else hipLaunchKernelGGL((splitk_reduce_gn_kernel<5, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      if (maxq == 1) SDMI_LAUNCH((splitk_reduce_gn_kernel<1, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else if (maxq == 3) SDMI_LAUNCH((splitk_reduce_gn_kernel<3, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
+      else SDMI_LAUNCH((splitk_reduce_gn_kernel<5, false>), grid, block, 0, stream, p, nsplit, magic_qpr);
     }
     SDMI_HIP_OK(hipGetLastError());
     psg.end();
@@ -538,7 +538,7 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     const double mn = (double)p.M * p.N;
     if (p.mode == EPI_HEADS) {
       ProfScope psh("splitk_reduce", 0.0, mn * (4.0 * nsplit + 2.0), stream);
-      hipLaunchKernelGGL(splitk_reduce_tiled_heads_kernel, dim3((unsigned)(quads / 256)), dim3(256), 0, stream, p, nsplit);
+      SDMI_LAUNCH(splitk_reduce_tiled_heads_kernel, dim3((unsigned)(quads / 256)), dim3(256), 0, stream, p, nsplit);
       SDMI_HIP_OK(hipGetLastError());
       return 0;
     }
@@ -556,14 +556,14 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
     const int rb_env = env_int("SDMI_REDUCE_BLOCK", 256);
     const int rb = (rb_env == 128 || (rb_env == 0 && quads / 256 < 512)) ? 128 : 256;
     if (coop) {
-      hipLaunchKernelGGL(splitk_reduce_tiled_kernel<true>, dim3((unsigned)(quads / 1024)), dim3(1024), 0, stream, p, nsplit);
+      SDMI_LAUNCH(splitk_reduce_tiled_kernel<true>, dim3((unsigned)(quads / 1024)), dim3(1024), 0, stream, p, nsplit);
       SDMI_HIP_OK(hipGetLastError());
       pst.end();
       if (p.pgn_applied) *p.pgn_applied = 1;
       if (range_check_enabled() && range_scan("GroupNorm fp16 output (split-K reduction)", p.pgn_out, (int64_t)p.M * p.N, stream)) return -1;
       return 0;
     }
-    hipLaunchKernelGGL(splitk_reduce_tiled_kernel<false>, dim3((unsigned)(quads / rb)), dim3(rb), 0, stream, p, nsplit);
+    SDMI_LAUNCH(splitk_reduce_tiled_kernel<false>, dim3((unsigned)(quads / rb)), dim3(rb), 0, stream, p, nsplit);
     SDMI_HIP_OK(hipGetLastError());
     pst.end();
     if (p.ln_out) return launch_layernorm(p.out_f32, p.ln_gamma, p.ln_beta, p.ln_out, p.M, p.N, p.ln_eps, stream);
@@ -572,7 +572,7 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   if (p.mode == EPI_HEADS) {
     const int64_t total_h = (int64_t)p.M * (p.N / 4);
     ProfScope psh("splitk_reduce", 0.0, (double)p.M * p.N * (4.0 * nsplit + 2.0), stream);
-    hipLaunchKernelGGL(splitk_reduce_heads_kernel, dim3((unsigned)((total_h + 255) / 256)), dim3(256), 0, stream, p, nsplit);
+    SDMI_LAUNCH(splitk_reduce_heads_kernel, dim3((unsigned)((total_h + 255) / 256)), dim3(256), 0, stream, p, nsplit);
     SDMI_HIP_OK(hipGetLastError());
     return 0;
   }
@@ -583,7 +583,7 @@ int launch_splitk_reduce(const IGemmParams& p, int nsplit, hipStream_t stream) {
   if (p.gn_n > 0) SDMI_CHECK(hw % 32 == 0, "GroupNorm statistics need Hout*Wout % 32 == 0");
   const int rpb = reduce_rows_per_block(p);
   ProfScope ps2("splitk_reduce", 0.0, (double)p.M * p.N * 4.0 * (nsplit + 1), stream);
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)cdiv(p.N / 4, 8), (unsigned)cdiv(p.M, rpb)), dim3(256), 0, stream, p, nsplit,
+  SDMI_LAUNCH(splitk_reduce_kernel, dim3((unsigned)cdiv(p.N / 4, 8), (unsigned)cdiv(p.M, rpb)), dim3(256), 0, stream, p, nsplit,
                      rpb);
   SDMI_HIP_OK(hipGetLastError());
   ps2.end();
@@ -776,6 +776,9 @@ static int tune_drain() {
   g_tuner.recs.clear();
   return 0;
 }
+bool tune_collecting() { return g_tuner.collecting; }
+static uint64_t g_tune_generation = 0;       // bumped whenever the table's contents may have changed (launch tapes were planned with it)
+uint64_t tune_generation() { return g_tune_generation; }
 int tune_end(const char* path, int* n_keys) {
   std::lock_guard<std::mutex> lk(g_tuner.mu);
   if (!g_tuner.collecting) return fail("sdmi_tune_end without sdmi_tune_begin");
@@ -797,6 +800,7 @@ int tune_end(const char* path, int* n_keys) {
     if (bc) g_tuner.table[kv.first] = {bc->tile, bc->splitk, best};
   }
   if (n_keys) *n_keys = (int)g_tuner.stats.size();
+  ++g_tune_generation;
   const std::string out = (path && *path) ? std::string(path) : Tuner::default_path();
   FILE* f = fopen(out.c_str(), "w");
   if (!f) return fail("cannot write the tuning table to " + out);

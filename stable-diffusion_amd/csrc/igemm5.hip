@@ -262,8 +262,8 @@ int launch_cfg5(const IGemmParams& p, int splitk, hipStream_t stream) {
   ProfScope ps(pname.c_str(), 2.0 * p.M * (double)p.N * k_alg,
                src_pix * cin_alg * 2.0 + (double)p.N * k_alg * 2.0 + (double)p.M * n_out * out_b + (p.residual ? (double)p.M * p.N * 4.0 : 0.0),
                stream, 2.0 * p.M * (double)p.N * p.K);
-  if (p.ksize == 1) hipLaunchKernelGGL((igemm5_kernel<BM, BN, NW, NS, KIND_1X1>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
-  else hipLaunchKernelGGL((igemm5_kernel<BM, BN, NW, NS, KIND_3X3>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+  if (p.ksize == 1) SDMI_LAUNCH((igemm5_kernel<BM, BN, NW, NS, KIND_1X1>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
+  else SDMI_LAUNCH((igemm5_kernel<BM, BN, NW, NS, KIND_3X3>), grid, block, 0, stream, q, tiles_m, tiles_n, kt_per_split);
   SDMI_HIP_OK(hipGetLastError());
   ps.end();
   if (nsplit > 1 && !q.splitk_fused) return launch_splitk_reduce(q, nsplit, stream);

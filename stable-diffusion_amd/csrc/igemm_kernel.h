@@ -373,9 +373,9 @@ int launch_cfg(const IGemmParams& p, bool dma, int splitk, hipStream_t stream) {
   const int kind = p.ksize == 1 ? KIND_1X1 : (p.up ? KIND_3X3_UP : KIND_3X3);
 #define SDMI_LAUNCH_KIND(K_)                                                                                        \
   do {                                                                                                              \
-    if (dma) hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, K_>), grid, block, 0, stream, q,   \
+    if (dma) SDMI_LAUNCH((igemm_kernel<BM, BN, WARPS_M, WARPS_N, true, NS, K_>), grid, block, 0, stream, q,   \
                                 tiles_m, tiles_n, kt_per_split);                                                    \
-    else hipLaunchKernelGGL((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, K_>), grid, block, 0, stream, q,       \
+    else SDMI_LAUNCH((igemm_kernel<BM, BN, WARPS_M, WARPS_N, false, 2, K_>), grid, block, 0, stream, q,       \
                             tiles_m, tiles_n, kt_per_split);                                                        \
   } while (0)
   if (kind == KIND_1X1) SDMI_LAUNCH_KIND(KIND_1X1);

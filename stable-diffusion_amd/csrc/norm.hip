@@ -237,7 +237,7 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
   const int nchunk = cdiv(p.HW, chunk_px);
   const double nel = (double)p.B * p.HW * C;
   ProfScope ps("groupnorm", 0.0, nel * 4.0 + nel * ((p.out_f16 ? 2.0 : 0.0) + (p.out_f32 ? 4.0 : 0.0) + (p.raw_f16 ? 2.0 : 0.0)), stream);
-  if (!p.skip_stats) hipLaunchKernelGGL(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
+  if (!p.skip_stats) SDMI_LAUNCH(gn_stats_kernel, dim3(nchunk, p.B), dim3(256), 0, stream, p, nchunk, chunk_px);
   if (!p.stats_only && (p.out_f16 || p.out_f32 || p.raw_f16 || p.out_lo || p.raw_lo)) {
     const int64_t quads = (int64_t)p.HW * (C / 4);
     static const int64_t u4_from = getenv("SDMI_GN_APPLY_U4_QUADS") ? atoll(getenv("SDMI_GN_APPLY_U4_QUADS")) : 300000;   // A/B knob; default: the 64x64 level of the 512 x 512 workload (327 680 quads per sample at 320 channels) and everything larger -- round 4, same-box A/B -0.03 ms per UNet call, 32x32 maps and below measured no gain (profiles/wt_stores_r04.txt)
@@ -249,10 +249,10 @@ int launch_groupnorm(const GroupNormParams& p, hipStream_t stream) {
     const int want_xcd = getenv("SDMI_GN_XCD") ? atoi(getenv("SDMI_GN_XCD")) : 0;
     if (quads >= u4_from) {
       const unsigned nb = (unsigned)((quads + 1023) / 1024);
-      hipLaunchKernelGGL(gn_apply_kernel<4>, dim3(nb, p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg, (want_xcd && (nb * p.B) % 8 == 0) ? 1 : 0);
+      SDMI_LAUNCH(gn_apply_kernel<4>, dim3(nb, p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg, (want_xcd && (nb * p.B) % 8 == 0) ? 1 : 0);
     } else {
       const unsigned nb = (unsigned)((quads + 255) / 256);
-      hipLaunchKernelGGL(gn_apply_kernel<1>, dim3(nb, p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg, (want_xcd && (nb * p.B) % 8 == 0) ? 1 : 0);
+      SDMI_LAUNCH(gn_apply_kernel<1>, dim3(nb, p.B), dim3(256), 0, stream, p, magic_nq, magic_cpg, (want_xcd && (nb * p.B) % 8 == 0) ? 1 : 0);
     }
   }
   SDMI_HIP_OK(hipGetLastError());
@@ -274,10 +274,10 @@ int launch_layernorm(const float* x, const float* gamma, const float* beta, f16*
   // Same per-lane order of the same terms: bit-identical.  SDMI_LN_SLOTS=0 = always the 5-slot kernel (A/B).
   const char* e_slots = getenv("SDMI_LN_SLOTS");
   const bool narrow = !(e_slots && atoi(e_slots) == 0);
-  if (narrow && C <= 512) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
-  else if (narrow && C <= 768) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
-  else if (C <= 1280) hipLaunchKernelGGL(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
-  else hipLaunchKernelGGL(layernorm_kernel<10>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  if (narrow && C <= 512) SDMI_LAUNCH(layernorm_kernel<2>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  else if (narrow && C <= 768) SDMI_LAUNCH(layernorm_kernel<3>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  else if (C <= 1280) SDMI_LAUNCH(layernorm_kernel<5>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
+  else SDMI_LAUNCH(layernorm_kernel<10>, grid, block, 0, stream, x, gamma, beta, out, M, C, eps, out_f32);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -286,7 +286,7 @@ int launch_cast_f16(const float* x, f16* out, f16* out_lo, int64_t n, hipStream_
   SDMI_CHECK(n % 4 == 0, "cast: n % 4 != 0");
   const int64_t n4 = n / 4;
   ProfScope ps("cast_f16", 0.0, (double)n * 6.0, stream);
-  hipLaunchKernelGGL(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, out, out_lo, n4);
+  SDMI_LAUNCH(cast_f16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, stream, x, out, out_lo, n4);
   SDMI_HIP_OK(hipGetLastError());
   if (range_check_enabled() && range_scan("fp16 cast of the residual stream / context", out, n, stream)) return -1;
   return 0;

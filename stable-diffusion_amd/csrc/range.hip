@@ -76,7 +76,7 @@ int range_scan(const char* what, const f16* p, int64_t n, hipStream_t stream) {
   if (!g_range.dev) SDMI_HIP_OK(hipMalloc((void**)&g_range.dev, 3 * sizeof(unsigned long long)));
   SDMI_HIP_OK(hipMemsetAsync(g_range.dev, 0, 3 * sizeof(unsigned long long), stream));
   const int64_t n8 = n / 8;
-  hipLaunchKernelGGL(range_scan_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, stream, p, n8, n, g_range.dev);
+  SDMI_LAUNCH(range_scan_kernel, dim3((unsigned)((n8 + 1 + 255) / 256)), dim3(256), 0, stream, p, n8, n, g_range.dev);
   SDMI_HIP_OK(hipGetLastError());
   unsigned long long h[3];
   SDMI_HIP_OK(hipMemcpyAsync(h, g_range.dev, sizeof h, hipMemcpyDeviceToHost, stream));

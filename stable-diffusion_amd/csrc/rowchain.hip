@@ -1151,20 +1151,20 @@ int launch_ff_tail(const FfTailParams& p, hipStream_t stream) {
   q.dbg = g_rc_dbg;
   const int abl = g_rc_abl % 10, nld = g_rc_abl >= 10 ? g_rc_abl / 10 : nld_env;      // 10 a + x: ablation x with a loader waves
   SDMI_CHECK(!head, "ff_tail timing build: the out-projection in front is not instantiated");
-#define RC_LAUNCH(NLD, ABL) hipLaunchKernelGGL((ff_tail_kernel<320, NLD, ABL>), grid, dim3(RC_NTC + 64 * NLD), 0, stream, q)
+#define RC_LAUNCH(NLD, ABL) SDMI_LAUNCH((ff_tail_kernel<320, NLD, ABL>), grid, dim3(RC_NTC + 64 * NLD), 0, stream, q)
 #define RC_ABL(NLD) switch (abl) { case 1: RC_LAUNCH(NLD, 1); break; case 2: RC_LAUNCH(NLD, 2); break; case 3: RC_LAUNCH(NLD, 3); break; default: RC_LAUNCH(NLD, 0); break; }
   if (nld == 1) { RC_ABL(1) } else { RC_ABL(2) }
 #else
   const int pf = env_int("SDMI_CHAIN_PF", 1);           // the prefetch wave (read per launch: A/B)
   if (nld_env == 1) {
-    if (head) hipLaunchKernelGGL((ff_tail_kernel<320, 1, 0, RC_NS, true>), grid, dim3(RC_NTC + 64), 0, stream, q);
-    else hipLaunchKernelGGL((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+    if (head) SDMI_LAUNCH((ff_tail_kernel<320, 1, 0, RC_NS, true>), grid, dim3(RC_NTC + 64), 0, stream, q);
+    else SDMI_LAUNCH((ff_tail_kernel<320, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
   } else if (pf) {
-    if (head) hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, true, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
-    else hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, false, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+    if (head) SDMI_LAUNCH((ff_tail_kernel<320, 2, 0, RC_NS, true, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+    else SDMI_LAUNCH((ff_tail_kernel<320, 2, 0, RC_NS, false, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
   } else {
-    if (head) hipLaunchKernelGGL((ff_tail_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 128), 0, stream, q);
-    else hipLaunchKernelGGL((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
+    if (head) SDMI_LAUNCH((ff_tail_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 128), 0, stream, q);
+    else SDMI_LAUNCH((ff_tail_kernel<320, 2>), grid, dim3(RC_NTC + 128), 0, stream, q);
   }
 #endif
   SDMI_HIP_OK(hipGetLastError());
@@ -1198,9 +1198,9 @@ int launch_st_head(const StHeadParams& p, hipStream_t stream) {
 #ifdef SDMI_RC_TIMING
   q.dbg = g_sh_dbg;
 #endif
-  if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 0>), grid, dim3(RC_NTC + 64), 0, stream, q);
-  else if (env_int("SDMI_CHAIN_PF", 1)) hipLaunchKernelGGL((st_head_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
-  else hipLaunchKernelGGL((st_head_kernel<320, 2, 0>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  if (nld == 1) SDMI_LAUNCH((st_head_kernel<320, 1, 0>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else if (env_int("SDMI_CHAIN_PF", 1)) SDMI_LAUNCH((st_head_kernel<320, 2, 0, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+  else SDMI_LAUNCH((st_head_kernel<320, 2, 0>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -1224,10 +1224,10 @@ int launch_st_mid(const StHeadParams& p, hipStream_t stream) {
 #ifdef SDMI_RC_TIMING
   q.dbg = g_sh_dbg;
 #endif
-  if (ctx) hipLaunchKernelGGL((st_head_kernel<320, 2, 1, RC_NS, true, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
-  else if (nld == 1) hipLaunchKernelGGL((st_head_kernel<320, 1, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
-  else if (env_int("SDMI_CHAIN_PF", 1)) hipLaunchKernelGGL((st_head_kernel<320, 2, 1, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
-  else hipLaunchKernelGGL((st_head_kernel<320, 2, 1>), grid, dim3(RC_NTC + 128), 0, stream, q);
+  if (ctx) SDMI_LAUNCH((st_head_kernel<320, 2, 1, RC_NS, true, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+  else if (nld == 1) SDMI_LAUNCH((st_head_kernel<320, 1, 1>), grid, dim3(RC_NTC + 64), 0, stream, q);
+  else if (env_int("SDMI_CHAIN_PF", 1)) SDMI_LAUNCH((st_head_kernel<320, 2, 1, RC_NS, true>), grid, dim3(RC_NTC + 192), 0, stream, q);
+  else SDMI_LAUNCH((st_head_kernel<320, 2, 1>), grid, dim3(RC_NTC + 128), 0, stream, q);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(256) image_u8_kernel(const float* img, unsigne
 int launch_image_u8(const float* img_nchw, unsigned char* out_nhwc, int B, int C, int H, int W, hipStream_t s) {
   SDMI_CHECK(img_nchw && out_nhwc && B > 0 && C > 0 && H > 0 && W > 0, "image_u8: bad arguments");
   const int64_t n = (int64_t)B * H * W;
-  hipLaunchKernelGGL(image_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img_nchw, out_nhwc, B, C, H, W);
+  SDMI_LAUNCH(image_u8_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, img_nchw, out_nhwc, B, C, H, W);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -124,7 +124,7 @@ int launch_dpm_step(const DpmStepParams& p, hipStream_t s) {
   SDMI_CHECK(p.n > 0 && p.eps_model && p.x && (p.m_out || p.x_next), "dpm_step: missing pointer");
   SDMI_CHECK(p.order == 1 || (p.order == 2 && p.m_prev), "dpm_step: order 1, or 2 with the previous model value");
   ProfScope ps("dpm_step", 0.0, (double)p.n * 4.0 * 6.0, s);
-  hipLaunchKernelGGL(dpm_step_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, s, p);
+  SDMI_LAUNCH(dpm_step_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, s, p);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -140,7 +140,7 @@ int launch_sampler_step(const SamplerStepParams& p, hipStream_t s) {
   const float sqrt_aprev = sqrtf(p.a_prev);
   const float dir_coef = sqrtf((1.0f - p.a_prev) - p.sigma * p.sigma);
   ProfScope ps("sampler_step", 0.0, (double)p.n * 4.0 * 6.0, s);
-  hipLaunchKernelGGL(sampler_step_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, s, p, sqrt_at, sqrt_aprev,
+  SDMI_LAUNCH(sampler_step_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, s, p, sqrt_at, sqrt_aprev,
                      dir_coef);
   SDMI_HIP_OK(hipGetLastError());
   return 0;

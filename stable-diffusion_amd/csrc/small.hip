@@ -465,7 +465,7 @@ int launch_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* o
   const float* freqs = nullptr;
   if (get_freqs(dim / 2, &freqs)) return -1;
   const int total = B * (dim / 2);
-  hipLaunchKernelGGL(temb_kernel, dim3(cdiv(total, 128)), dim3(128), 0, s, t_i64, t_f32, freqs, out, B, dim);
+  SDMI_LAUNCH(temb_kernel, dim3(cdiv(total, 128)), dim3(128), 0, s, t_i64, t_f32, freqs, out, B, dim);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -480,10 +480,10 @@ int launch_small_linear(const float* in, int ld_in, const float* w, const float*
   const size_t lds = (size_t)B * K * sizeof(float);
   const bool al16 = ((((uintptr_t)in | (uintptr_t)w) & 15) == 0);
   if (env_lds && K <= 1280 && lds <= 64 * 1024 && al16) {           // every input row of the block in LDS, <= 5 weight quads per lane
-    if (K <= 512) hipLaunchKernelGGL(small_linear_lds_kernel<2>, dim3(cdiv(N, 8)), dim3(512), lds, s, in, ld_in, w, bias, out, ld_out, B, N, K, silu_in);
-    else hipLaunchKernelGGL(small_linear_lds_kernel<5>, dim3(cdiv(N, 8)), dim3(512), lds, s, in, ld_in, w, bias, out, ld_out, B, N, K, silu_in);
+    if (K <= 512) SDMI_LAUNCH(small_linear_lds_kernel<2>, dim3(cdiv(N, 8)), dim3(512), lds, s, in, ld_in, w, bias, out, ld_out, B, N, K, silu_in);
+    else SDMI_LAUNCH(small_linear_lds_kernel<5>, dim3(cdiv(N, 8)), dim3(512), lds, s, in, ld_in, w, bias, out, ld_out, B, N, K, silu_in);
   } else {
-    hipLaunchKernelGGL(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, ld_in, w, bias, out, ld_out, B, N, K,
+    SDMI_LAUNCH(small_linear_kernel, dim3(cdiv(N, 4)), dim3(256), 0, s, in, ld_in, w, bias, out, ld_out, B, N, K,
                        silu_in);
   }
   SDMI_HIP_OK(hipGetLastError());
@@ -494,7 +494,7 @@ int launch_conv_in(const float* x, const float* w, const float* bias, float* out
                    hipStream_t s) {
   SDMI_CHECK(Cin * 9 <= CI_MAXK, "conv_in: in_channels <= 16");
   ProfScope ps("conv_in_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
-  hipLaunchKernelGGL(conv_in_kernel, dim3(cdiv(B * H * W, CI_PIX)), dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, Cout);
+  SDMI_LAUNCH(conv_in_kernel, dim3(cdiv(B * H * W, CI_PIX)), dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, Cout);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -510,10 +510,10 @@ int launch_conv_out(const float* h, const float* w, const float* bias, float* ou
   const bool al16 = ((((uintptr_t)h | (uintptr_t)w | (uintptr_t)out) & 15) == 0);
   if (env_co4 && W % COP == 0 && Cin <= 512 && al16) {       // (out rows of W floats at x0 % 4 == 0: 16-byte aligned stores)
     const int groups = B * H * (W / COP);
-    if (Cout <= 4) hipLaunchKernelGGL(conv_out4_kernel<4>, dim3(cdiv(groups, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
-    else hipLaunchKernelGGL(conv_out4_kernel<8>, dim3(cdiv(groups, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+    if (Cout <= 4) SDMI_LAUNCH(conv_out4_kernel<4>, dim3(cdiv(groups, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+    else SDMI_LAUNCH(conv_out4_kernel<8>, dim3(cdiv(groups, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
   } else {
-    hipLaunchKernelGGL(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
+    SDMI_LAUNCH(conv_out_kernel, dim3(cdiv(B * H * W, 4)), dim3(256), 0, s, h, w, bias, out, B, H, W, Cin, Cout);
   }
   SDMI_HIP_OK(hipGetLastError());
   return 0;
@@ -524,7 +524,7 @@ int launch_embed_tokens(const int64_t* ids, const float* tok_emb, const float* p
                         int vocab, hipStream_t s) {
   SDMI_CHECK(C % 4 == 0 && M >= 1 && L >= 1 && vocab >= 1, "embed_tokens: C % 4");
   const int64_t total = (int64_t)M * (C / 4);
-  hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ids, tok_emb, pos_emb, out, M,
+  SDMI_LAUNCH(embed_tokens_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, ids, tok_emb, pos_emb, out, M,
                      L, C, vocab);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
@@ -532,7 +532,7 @@ int launch_embed_tokens(const int64_t* ids, const float* tok_emb, const float* p
 
 int launch_quick_gelu(const float* x, f16* out, int64_t n, hipStream_t s) {
   SDMI_CHECK(n % 4 == 0, "quick_gelu: n % 4");
-  hipLaunchKernelGGL(quick_gelu_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n / 4);
+  SDMI_LAUNCH(quick_gelu_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, x, out, n / 4);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -541,7 +541,7 @@ int launch_pointwise_nchw(const float* x, const float* w, const float* bias, flo
                           float in_scale, hipStream_t s) {
   SDMI_CHECK(Cin >= 1 && Cin <= PW_MAXC && Cout >= 1, "pointwise conv: 1 <= Cin <= 16");
   const int64_t total = (int64_t)B * HW;
-  hipLaunchKernelGGL(pointwise_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, out, B, Cin,
+  SDMI_LAUNCH(pointwise_nchw_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, w, bias, out, B, Cin,
                      Cout, HW, in_scale);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
@@ -550,14 +550,14 @@ int launch_pointwise_nchw(const float* x, const float* w, const float* bias, flo
 int launch_softmax_rows(const float* S, f16* P, int rows, int cols, int lds, int ldp, float scale, hipStream_t s) {
   SDMI_CHECK(cols % 4 == 0 && lds % 4 == 0 && ldp % 4 == 0 && rows >= 1, "softmax rows: cols % 4");
   ProfScope ps("softmax_rows", 0.0, (double)rows * cols * 6.0, s);
-  hipLaunchKernelGGL(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, P, cols, lds, ldp, scale);
+  SDMI_LAUNCH(softmax_rows_kernel, dim3(rows), dim3(256), 0, s, S, P, cols, lds, ldp, scale);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
 
 int launch_pack_conv_weight(const float* w, f16* dst, int O, int I, int KH, int KW, hipStream_t s) {
   const int64_t total = (int64_t)O * I * KH * KW;
-  hipLaunchKernelGGL(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, KH, KW);
+  SDMI_LAUNCH(pack_conv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, KH, KW);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -572,7 +572,7 @@ __global__ void __launch_bounds__(256) prefetch_lines_kernel(const unsigned* p, 
 int launch_prefetch_lines(const void* ptr, int64_t bytes, hipStream_t s) {
   const long long nlines = bytes / 128;
   if (nlines <= 0) return 0;
-  hipLaunchKernelGGL(prefetch_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, s, (const unsigned*)ptr, nlines);
+  SDMI_LAUNCH(prefetch_lines_kernel, dim3((unsigned)((nlines + 255) / 256)), dim3(256), 0, s, (const unsigned*)ptr, nlines);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
@@ -580,19 +580,19 @@ int launch_prefetch_lines(const void* ptr, int64_t bytes, hipStream_t s) {
 int launch_pack_conv_split3(const float* w, f16* dst, int O, int I, int KH, int KW, hipStream_t s) {
   SDMI_CHECK(I % 64 == 0, "split-fp16 conv pack: input channels % 64");
   const int64_t total = (int64_t)O * 3 * I * KH * KW;
-  hipLaunchKernelGGL(pack_conv_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, KH, KW);
+  SDMI_LAUNCH(pack_conv_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, KH, KW);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
 int launch_pack_conv_out(const float* w, float* dst, int O, int I, hipStream_t s) {
   const int64_t total = (int64_t)O * I * 9;
-  hipLaunchKernelGGL(pack_conv_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, 3, 3);
+  SDMI_LAUNCH(pack_conv_f32_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, O, I, 3, 3);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
 int launch_pack_rows(const float* w, f16* dst, int rows, int cols, int dst_row0, int dst_ld, hipStream_t s) {
   const int64_t total = (int64_t)rows * cols;
-  hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, rows, cols,
+  SDMI_LAUNCH(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, rows, cols,
                      dst_row0, dst_ld);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
@@ -616,20 +616,20 @@ __global__ void __launch_bounds__(256) ln_fold_prep_kernel(const f16* w, int N, 
 int launch_ln_fold_prep(const f16* w, int N, int K, int ldw, const float* gamma, const float* beta, const float* bias, float* cs,
                         float* d, hipStream_t s) {
   SDMI_CHECK(w && gamma && beta && cs && d && N > 0 && K > 0 && ldw >= K, "ln_fold_prep: bad arguments");
-  hipLaunchKernelGGL(ln_fold_prep_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s, w, N, K, ldw, gamma, beta, bias, cs, d);
+  SDMI_LAUNCH(ln_fold_prep_kernel, dim3((unsigned)cdiv(N, 4)), dim3(256), 0, s, w, N, K, ldw, gamma, beta, bias, cs, d);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
 int launch_pack_split3(const float* w, f16* dst, int N, int K, hipStream_t s) {
   const int64_t total = (int64_t)N * K;
-  hipLaunchKernelGGL(pack_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, N, K);
+  SDMI_LAUNCH(pack_split3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, dst, N, K);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }
 int launch_pack_geglu(const float* w, const float* bias, f16* wdst, float* bdst, int N, int K, hipStream_t s) {
   SDMI_CHECK(N % 64 == 0, "GEGLU pack: N % 64");
   const int64_t total = (int64_t)N * K;
-  hipLaunchKernelGGL(pack_geglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, bias, wdst, bdst, N, K);
+  SDMI_LAUNCH(pack_geglu_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, w, bias, wdst, bdst, N, K);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

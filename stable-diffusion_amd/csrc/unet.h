@@ -3,6 +3,7 @@
 #include <stdlib.h>
 
 #include <map>
+#include <memory>
 #include <string>
 #include <utility>
 #include <vector>
@@ -125,7 +126,7 @@ struct FwdBase {
     long long* blk = P<long long>(acc_words + SPLITK_CNT_INTS / 2);
     gn_acc = with_gn ? blk : nullptr;
     splitk_cnt = (int*)(blk + acc_words);
-    if (!dry) SDMI_HIP_OK(hipMemsetAsync(blk, 0, (acc_words + SPLITK_CNT_INTS / 2) * sizeof(long long), s));
+    if (!dry) SDMI_HIP_OK(memset_async(blk, 0, (acc_words + SPLITK_CNT_INTS / 2) * sizeof(long long), s));
     splitk_ws_floats = splitk_floats;
     splitk_ws = P<float>((size_t)splitk_floats);
     splitk_ws2_floats = splitk_floats / 2;               // (always: the workspace size must not depend on the side stream)
@@ -336,6 +337,23 @@ class UNet {
   // ... and SpatialTransformer heads (GroupNorm-apply -> proj_in -> q | k | v of the first transformer block) likewise.  SDMI_ST_HEAD=0
   // restores the three launches (bit-identical outputs; A/B).
   bool st_head_ = true;
+
+  // ---- launch tapes (tape.h): the launch list of a (shape, workspace, mode, knobs) recorded once and replayed
+  struct TapeKey {
+    int B = 0, H = 0, W = 0, Lctx = 0, mode = 0;         // mode: 0 timestep-table row (hinted), 1 int64 timesteps, 2 fp32 timesteps
+    const void* ws = nullptr; int64_t ws_bytes = 0; bool have_ctx = false;
+    uint64_t env = 0, weights_gen = 0, ctx_gen = 0;
+    bool operator==(const TapeKey& o) const {
+      return B == o.B && H == o.H && W == o.W && Lctx == o.Lctx && mode == o.mode && ws == o.ws && ws_bytes == o.ws_bytes &&
+             have_ctx == o.have_ctx && env == o.env && weights_gen == o.weights_gen && ctx_gen == o.ctx_gen;
+    }
+  };
+  std::vector<std::pair<TapeKey, std::unique_ptr<Tape>>> tapes_;     // (most recently used last; at most kMaxTapes)
+  static constexpr size_t kMaxTapes = 12;
+  uint64_t weights_gen_ = 0, ctx_gen_ = 0;
+ public:
+  uint64_t tape_hits_ = 0, tape_records_ = 0;            // (sdmi_unet_tape_stats: tests / bench)
+ private:
 
   std::vector<std::vector<Layer>> input_blocks_, output_blocks_;
   std::vector<Layer> middle_;
