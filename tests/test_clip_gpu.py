@@ -13,7 +13,10 @@ pytestmark = pytest.mark.gpu
 
 from oracle import clip_ref  # noqa: E402
 
-CLIP_TOL = 4e-3
+# Round 6: 1.25 x the worst error measured over weight seeds 0 (the HF goldens), 1 and 2 (against the oracle, pinned to HF's
+# CLIPTextModel at 3e-6 by oracle/make_golden_clip.py).  Measured (pass I, MI355X): 3.13e-3 (sd_b2, seed 0), 3.67e-3 (seed 1), 3.42e-3 (seed 2),
+# rms 6.4 - 7.6e-4 on a LayerNorm output of rms 1 -> 1.25 x 3.67e-3.  (Rounds 1-5 carried 4e-3 on seed 0 alone.)
+CLIP_TOL = 4.6e-3
 CFGS = {'tiny': clip_ref.TINY_CLIP, 'sd': clip_ref.SD_CLIP}
 _models = {}
 
@@ -67,6 +70,18 @@ def test_clip_matches_hf_golden(case, golden_dir):
     print(f'[clip {case}] HIP-vs-HF(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e} |x|max {ref.abs().max():.3f} '
           f'nan={bool(torch.isnan(out).any())}', flush=True)
     assert out.shape == ref.shape and out.dtype == torch.float32
+    assert float(err.max()) <= CLIP_TOL
+
+
+@pytest.mark.parametrize('wseed', [1, 2])
+def test_clip_other_weight_seeds(wseed):
+    """The SD text model under weight seeds the goldens do not use, against the oracle restatement on the same token ids."""
+    cfg = clip_ref.SD_CLIP
+    m, sd = _model('sd', wseed)
+    ids = clip_ref.make_clip_ids(cfg, 2, 77, seed=5)
+    ref = clip_ref.clip_text_forward(sd, cfg, ids)
+    err = (m.encode_ids(ids.cuda()).float().cpu() - ref).abs()
+    print(f'[clip sd_b2 weight seed {wseed}] HIP-vs-oracle(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e}', flush=True)
     assert float(err.max()) <= CLIP_TOL
 
 

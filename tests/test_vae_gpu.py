@@ -18,8 +18,11 @@ pytestmark = pytest.mark.gpu
 
 from oracle.vae_ref import SD_VAE, SMALL_VAE, TINY_VAE, make_vae_inputs, make_vae_state_dict  # noqa: E402
 
-DEC_TOL = 4e-3
-ENC_TOL = 4e-3
+# Round 6: 1.25 x the worst error MEASURED over weight seeds 0 (the reference goldens), 1 and 2 (against the oracle, which the
+# golden script pins to the reference at 0.0) -- rounds 1-5 carried 4e-3 for both.  Measured worst (pass H / I, MI355X): decode 2.34e-3
+# (sd_64x64, seed 0), encode moments 2.77e-3 (sd_256x256, seed 0); seeds 1 / 2 (test_vae_other_weight_seeds): decode <= 1.90e-3, encode <= 2.07e-3.
+DEC_TOL = 3.0e-3
+ENC_TOL = 3.5e-3
 CFGS = {'tiny': TINY_VAE, 'small': SMALL_VAE, 'sd': SD_VAE}
 _models = {}
 
@@ -78,6 +81,28 @@ def test_vae_encode_matches_reference_golden(case, golden_dir):
     post = m.encode(x.cuda())
     assert torch.equal(post.mode(), mom[:, :cfg.embed_dim])
     assert torch.allclose(post.std, torch.exp(0.5 * mom[:, cfg.embed_dim:].clamp(-30.0, 20.0)))
+
+
+@pytest.mark.parametrize('wseed', [1, 2])
+def test_vae_other_weight_seeds(wseed):
+    """The SD first stage under weight seeds the goldens do not use, against the oracle on the same inputs (oracle == reference Encoder / Decoder
+    at 0.0 on every golden: oracle/make_golden_vae.py): decode 16x24 and 32x32 latents, encode a 64x64 image."""
+    from oracle import vae_ref
+    cfg = SD_VAE
+    m = _model('sd', wseed)
+    sd = make_vae_state_dict(cfg, wseed)
+    for h, w in ((16, 24), (32, 32)):
+        lat = make_vae_inputs(cfg, 1, h, w, seed=3)
+        ref = vae_ref.vae_decode(sd, cfg, lat)
+        err = (m.decode(lat.cuda()).float().cpu() - ref).abs()
+        print(f'[vae decode sd_{h}x{w} weight seed {wseed}] HIP-vs-oracle(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e}', flush=True)
+        assert float(err.max()) <= DEC_TOL
+    g = torch.Generator().manual_seed(4)
+    x = torch.rand(1, cfg.in_channels, 64, 64, generator=g) * 2 - 1
+    ref = vae_ref.vae_encode_moments(sd, cfg, x)
+    err = (m.encode_moments(x.cuda()).float().cpu() - ref).abs()
+    print(f'[vae encode sd_64x64 weight seed {wseed}] HIP-vs-oracle(fp32) max-abs {err.max():.3e} rms {err.pow(2).mean().sqrt():.3e}', flush=True)
+    assert float(err.max()) <= ENC_TOL
 
 
 def test_vae_decode_is_repeatable_and_scaled():
