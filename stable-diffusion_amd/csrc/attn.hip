@@ -291,7 +291,13 @@ __device__ __forceinline__ float sum_across_halves(float x) {
 // ABL != 0: timing-only ablations (wrong results) that price one ingredient of the loop at a time (tools/attn_ablate.py):
 //   1 no per-tile wait + barrier, 2 no DMA issue, 3 exp2 replaced by a move, 4 no PV MFMAs, 5 no QK^T MFMAs,
 //   6 K / V^T fragments read from LDS once (first tile) only
-template <int D, int NW, int NS, bool CAUSAL, int ABL = 0>
+// KVS = 2 (round 6): the KEY range is split inside the workgroup.  NW = 16 waves: waves 0..7 and 8..15 serve the SAME 256 queries, group g over
+// keys [g * nkv / 2, (g + 1) * nkv / 2) with its own LDS-DMA ring; at the end group 1 hands {O^T, running maximum} to group 0 through LDS and
+// group 0 merges the two softmax partials (O = 2^(m0 - m) O0 + 2^(m1 - m) O1; the denominator is a row of O^T, see ONES) and stores.  Why: with one
+// 8-wave workgroup per CU a SIMD holds two waves and 39 % of their cycles are waits (ds_read / barrier / vmcnt, profiles/pmc_by_kernel_r06.txt)
+// that nothing overlaps; 4 waves per SIMD do overlap them, and a grid of 256 workgroups cannot be doubled along the queries without
+// re-staging K / V per workgroup (round 2: 4-wave workgroups at two per CU, 107 us).  The per-wave instruction stream is unchanged.
+template <int D, int NW, int NS, bool CAUSAL, int ABL = 0, int KVS = 1>
 __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DKS = (D + 15) / 16;   // k-steps of 16 over the head dim (QK^T)
@@ -306,17 +312,23 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   constexpr bool ONES = VROWS > D;
   constexpr int PK = NCH * 8, PV = ONES ? D / 8 : DVT * 4, PT = PK + PV;   // DMA pieces (8 rows x 128 B each) per tile
   static_assert(D % 8 == 0, "a DMA piece is 8 rows");
-  constexpr int PPW = (PT + NW - 1) / NW;                          // per wave (the surplus re-issues the last piece)
-  static_assert(NS >= 2 && NS * STAGE <= 160 * 1024, "LDS budget");
+  constexpr int NWQ = NW / KVS;                                    // query waves (waves per key group)
+  static_assert(KVS == 1 || (KVS == 2 && !CAUSAL && NW % 2 == 0), "key split: two groups, no causal mask");
+  constexpr int PPW = (PT + NWQ - 1) / NWQ;                        // per wave (the surplus re-issues the last piece)
+  static_assert(NS >= 2 && KVS * NS * STAGE <= 160 * 1024, "LDS budget");
+  static_assert(KVS == 1 || NWQ * (DVT * 16 + 2) * 64 * 4 <= KVS * NS * STAGE, "the hand-over of the key groups lives in the (drained) rings");
 
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * STAGE];
+  __shared__ __attribute__((aligned(16))) unsigned char smem_all[KVS * NS * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = KVS == 1 ? 0 : wave_all / NWQ;                   // key group of this wave
+  const int wave = KVS == 1 ? wave_all : wave_all - grp * NWQ;     // query slice inside the workgroup
+  unsigned char* const smem = smem_all + grp * (NS * STAGE);       // this group's ring
   const int l31 = lane & 31, lg = lane >> 5;
   int bh, qt;
   head_of_block(bh, qt);
-  const int q0 = qt * (32 * NW) + wave * 32;
+  const int q0 = qt * (32 * NWQ) + wave * 32;
   const f16* Qg = p.q + (size_t)bh * p.nq * D;
   constexpr int OOB = (int)0x80000000;
   const __amdgpu_buffer_rsrc_t rsrc_k =
@@ -339,7 +351,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   bool pv_isk[PPW];
 #pragma unroll
   for (int j = 0; j < PPW; ++j) {
-    const int q = min(wave + j * NW, PT - 1);
+    const int q = min(wave + j * NWQ, PT - 1);
     const int r8 = lane >> 3, cp = lane & 7;
     if (q < PK) {
       const int c = q >> 3, row = (q & 7) * 8 + r8;               // LDS row; it holds key perm(row) of the tile
@@ -377,15 +389,21 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
     for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
   float m_run = -1e30f, l_run = 0.f;
   if (ONES) {
-    for (int e = tid; e < NS * (VROWS - D) * 8; e += NW * 64) {           // 16-byte chunks of the padding rows of every stage
+    for (int e = tid; e < KVS * NS * (VROWS - D) * 8; e += NW * 64) {     // 16-byte chunks of the padding rows of every stage (of every ring)
       const int st = e / ((VROWS - D) * 8), rc = e - st * ((VROWS - D) * 8), row = D + (rc >> 3);
       const unsigned one2 = row == D ? 0x3C003C00u : 0u;                   // fp16 1.0 pairs
-      *(u32x4*)(smem + st * STAGE + (KROWS + row) * 128 + (rc & 7) * 16) = u32x4{one2, one2, one2, one2};
+      *(u32x4*)(smem_all + st * STAGE + (KROWS + row) * 128 + (rc & 7) * 16) = u32x4{one2, one2, one2, one2};
     }
   }
   const float sc = p.scale * 1.4426950408889634f;   // scores are compared / exponentiated in log2 units
 
-  const int nt = (p.nkv + KVT - 1) / KVT;
+  const int nt_all = (p.nkv + KVT - 1) / KVT;
+  const int nt = nt_all / KVS;                                 // (the launcher takes KVS = 2 only for an even tile count)
+  const int t_first = grp * nt;                                // this group's first key tile
+  if (KVS > 1) {
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) pv_off[j] += t_first * pv_step[j];       // (the out-of-range marker has a zero step)
+  }
 #pragma unroll
   for (int s2 = 0; s2 < NS - 1; ++s2) issue_tile(s2);          // (tiles past nt read out of range: zeros, never consumed)
   wait_dma<PPW*(NS - 2)>();
@@ -414,7 +432,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
         s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
       }
     }
-    const int kv0 = t * KVT;
+    const int kv0 = (t_first + t) * KVT;
     if (CAUSAL || kv0 + KVT > p.nkv) {
       asm volatile("; masked tile" ::: "memory");
       const int qlim = CAUSAL ? (q0 + l31) : 0x7fffffff;
@@ -483,6 +501,30 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
     nxt = (nxt + 1 == NS) ? 0 : nxt + 1;
   }
   wait_dma<0>();
+
+  if constexpr (KVS == 2) {
+    // ---- merge the two key groups: group 1 parks {O^T, m, l} in LDS (lane-contiguous: no bank conflicts), group 0 folds them in ----
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");       // every DMA of both rings has landed, every fragment is read: the rings are free
+    float* const xch = (float*)smem_all + (size_t)wave * ((DVT * 16 + 2) * 64) + lane;
+    if (grp == 1) {
+#pragma unroll
+      for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) xch[(dt * 16 + r) * 64] = o[dt][r];
+      xch[(DVT * 16) * 64] = m_run;
+      xch[(DVT * 16 + 1) * 64] = l_run;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    if (grp == 1) return;
+    const float m1 = xch[(DVT * 16) * 64], l1 = xch[(DVT * 16 + 1) * 64];
+    const float m = fmaxf(m_run, m1);
+    const float a0 = __builtin_amdgcn_exp2f(m_run - m), a1 = __builtin_amdgcn_exp2f(m1 - m);
+#pragma unroll
+    for (int dt = 0; dt < DVT; ++dt)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[dt][r] = a0 * o[dt][r] + a1 * xch[(dt * 16 + r) * 64];
+    l_run = a0 * l_run + a1 * l1;
+  }
 
   float l_tot;
   if (ONES) {            // row D of O^T: tile D / 32, register and lane half of local row D % 32
@@ -773,6 +815,9 @@ __global__ void __launch_bounds__(512) attn_pp_kernel(const AttnParams p) {
 #define SDMI_EXP_ENV(name, def) (def)
 #endif
 
+#ifndef SDMI_ATTN_KVS_DEFAULT
+#define SDMI_ATTN_KVS_DEFAULT 1
+#endif
 template <int D>
 int launch_d(const AttnParams& p, hipStream_t stream) {
   // Long sequences (> 1024 queries): 8 waves share each K/V tile.  Short ones (the 32x32 / 16x16 / 8x8 levels) are
@@ -793,6 +838,12 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
   ProfScope ps((p.nkv >= 256 ? pname_long : pname_short).c_str(), 4.0 * p.BH * (double)p.nq * p.nkv * D, 2.0 * p.BH * D * (2.0 * p.nq + 2.0 * p.nkv), stream);
   static const int use_v1 = SDMI_EXP_ENV("SDMI_ATTN_V1", 0);     // A/B: the register-staged kernel (the product build keeps it for unaligned K / V only)
   constexpr int DNS = (D > 128) ? 3 : 4;                        // LDS-DMA ring depth (D = 160: 3 x 44 KB)
+  // round 6: the key range split over two 8-wave groups of ONE 16-wave workgroup (attn_dma_kernel KVS = 2): d = 40 self-attention of the
+  // 64 x 64 level (an even number of 64-key tiles, 16 .. 32 of them per group: 2048 .. 4096 keys).  Same-box A/B (profiles/attn_kvsplit_r06.txt): 78.0 -> 73.9 us
+  // per launch at 4096 keys, UNet call -0.019 ms at 64 x 64 but +0.06 ms at 96 x 96 (9216 keys: the 8-wave kernel stays there).
+  // SDMI_ATTN_KVS=0 restores the 8-wave kernel everywhere, =2 forces the split for every even tile count >= 32 (A/B; read per launch)
+  const int kvs_env = getenv("SDMI_ATTN_KVS") ? atoi(getenv("SDMI_ATTN_KVS")) : SDMI_ATTN_KVS_DEFAULT;
+  const bool kvs2 = D == 40 && nw == 8 && !p.causal && !p.pingpong && p.nkv % (2 * KVT) == 0 && p.nkv >= 32 * KVT && kvs_env != 0 && (p.nkv <= 64 * KVT || kvs_env == 2);
   if (!use_v1 && !p.causal && (p.nkv * D) % 8 == 0) {
     // timing-only ablations (WRONG results: each removes one ingredient of the loop, tools/attn_ablate.py) exist only in a build with
     // -DSDMI_ABLATE (SDMI_CXXFLAGS=-DSDMI_ABLATE SDMI_LIB_OUT=libsdmi_ablate.so python stable-diffusion_amd/build.py): no environment
@@ -819,6 +870,8 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
     } else if (nw == 8 && p.pingpong && DNS >= 4) {
       if constexpr (DNS >= 4) SDMI_LAUNCH((attn_pp_kernel<D, DNS>), grid, dim3(512), 0, stream, p);
 #endif
+    } else if (nw == 8 && kvs2) {
+      if constexpr (D == 40) SDMI_LAUNCH((attn_dma_kernel<D, 16, DNS, false, 0, 2>), grid, dim3(1024), 0, stream, p);
     } else if (nw == 8) SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
     else if (nw == 4) SDMI_LAUNCH((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
     else SDMI_LAUNCH((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);

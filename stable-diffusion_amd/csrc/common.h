@@ -426,8 +426,11 @@ int launch_cast_f16(const float* x, f16* out, f16* out_lo, int64_t n, hipStream_
 int launch_timestep_embedding(const int64_t* t_i64, const float* t_f32, float* out, int B, int dim, hipStream_t s);
 int launch_small_linear(const float* in, int ld_in, const float* w, const float* bias, float* out, int ld_out,
                         int B, int N, int K, int silu_in, hipStream_t s);
+// gn_*: GroupNorm statistics of the output for up to two consuming GroupNorms (accumulator regions, channels per group, channel offset of
+// this tensor inside the GroupNorm's input: IGemmParams::gn_acc / gn_cpg / gn_cbase); needs H * W % 16 == 0
 int launch_conv_in(const float* x_nchw, const float* w, const float* bias, float* out_nhwc, int B, int Cin, int H,
-                   int W, int Cout, hipStream_t s);
+                   int W, int Cout, hipStream_t s, int gn_n = 0, long long* const* gn_acc = nullptr, const int* gn_cpg = nullptr,
+                   const int* gn_cbase = nullptr);
 int launch_conv_out(const float* h_nhwc, const float* w_khwc, const float* bias, float* out_nchw, int B, int H, int W,
                     int Cin, int Cout, hipStream_t s);
 

@@ -121,9 +121,22 @@ __global__ void __launch_bounds__(512) small_linear_lds_kernel(const float* in, 
 constexpr int CI_PIX = 16;
 constexpr int CI_MAXK = 9 * 16;   // Cin <= 16
 // x NCHW fp32 -> out NHWC fp32, 3x3 pad 1
+// Round 6: the GroupNorm statistics of the output for up to two consuming GroupNorms (ConvInStats; the same fixed-point accumulators the igemm
+// epilogues feed: per thread the {sum, sum of squares} of its channel over the block's 16 pixels, combined per group in LDS as integers, one
+// atomic set per (group, word) and block) -- the two GroupNorms that read conv_in's output (input_blocks.1.0, and output_blocks.<last>.0 through the
+// skip concat) no longer need the statistics kernel.  A block's 16 pixels lie inside one sample (H * W % 16 == 0: the launcher checks).
+struct ConvInStats {
+  int n = 0;
+  long long* acc[2] = {nullptr, nullptr};
+  int cpg[2] = {1, 1}, cbase[2] = {0, 0};
+};
 __global__ void __launch_bounds__(256) conv_in_kernel(const float* x, const float* w, const float* bias, float* out, int B,
-                                                      int Cin, int H, int W, int Cout) {
+                                                      int Cin, int H, int W, int Cout, const ConvInStats st) {
   __shared__ float patch[CI_PIX][CI_MAXK];
+  __shared__ unsigned long long s_gn[2][32][GN_WORDS];
+  if (st.n > 0) {
+    for (int i = threadIdx.x; i < 2 * 32 * GN_WORDS; i += 256) (&s_gn[0][0][0])[i] = 0ull;
+  }
   const int tid = threadIdx.x;
   const int K = Cin * 9;
   const int M = B * H * W;
@@ -155,6 +168,27 @@ __global__ void __launch_bounds__(256) conv_in_kernel(const float* x, const floa
 #pragma unroll
     for (int pi = 0; pi < CI_PIX; ++pi)
       if (m0 + pi < M) out[(size_t)(m0 + pi) * Cout + co] = acc[pi];
+    if (st.n > 0) {
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int pi = 0; pi < CI_PIX; ++pi)
+        if (m0 + pi < M) { s1 += acc[pi]; s2 += acc[pi] * acc[pi]; }
+      for (int tg = 0; tg < st.n; ++tg) {
+        const int g = (st.cbase[tg] + co) / st.cpg[tg];
+        gn_acc_add(&s_gn[tg][g][0], s1);
+        gn_acc_add(&s_gn[tg][g][2], s2);
+      }
+    }
+  }
+  if (st.n > 0) {
+    __syncthreads();
+    const int b = m0 / (H * W), slot = blockIdx.x & (GN_SLOTS - 1);
+    for (int e = tid; e < st.n * 32 * GN_WORDS; e += 256) {
+      const unsigned long long wv = (&s_gn[0][0][0])[e];
+      if (wv == 0ull) continue;
+      const int word = e % GN_WORDS, g = (e / GN_WORDS) % 32, tg = e / (GN_WORDS * 32);
+      atomicAdd((unsigned long long*)st.acc[tg] + ((size_t)(b * 32 + g) * GN_SLOTS + slot) * GN_STRIDE + word, wv);
+    }
   }
 }
 
@@ -491,10 +525,16 @@ int launch_small_linear(const float* in, int ld_in, const float* w, const float*
 }
 
 int launch_conv_in(const float* x, const float* w, const float* bias, float* out, int B, int Cin, int H, int W, int Cout,
-                   hipStream_t s) {
+                   hipStream_t s, int gn_n, long long* const* gn_acc, const int* gn_cpg, const int* gn_cbase) {
   SDMI_CHECK(Cin * 9 <= CI_MAXK, "conv_in: in_channels <= 16");
+  ConvInStats st;
+  if (gn_n > 0) {
+    SDMI_CHECK(gn_n <= 2 && (H * W) % CI_PIX == 0, "conv_in statistics: at most two GroupNorm targets, H * W % 16 == 0");
+    st.n = gn_n;
+    for (int i = 0; i < gn_n; ++i) { st.acc[i] = gn_acc[i]; st.cpg[i] = gn_cpg[i]; st.cbase[i] = gn_cbase[i]; }
+  }
   ProfScope ps("conv_in_f32", 2.0 * B * H * W * (double)Cout * Cin * 9, (double)B * H * W * (Cin + Cout) * 4.0, s);
-  SDMI_LAUNCH(conv_in_kernel, dim3(cdiv(B * H * W, CI_PIX)), dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, Cout);
+  SDMI_LAUNCH(conv_in_kernel, dim3(cdiv(B * H * W, CI_PIX)), dim3(256), 0, s, x, w, bias, out, B, Cin, H, W, Cout, st);
   SDMI_HIP_OK(hipGetLastError());
   return 0;
 }

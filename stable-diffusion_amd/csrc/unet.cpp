@@ -1125,8 +1125,16 @@ int UNet::run(const float* x, const int64_t* t_i64, const float* t_f32, const fl
       Act h;
       {
         Layer& L = input_blocks_[0][0];
-        h = f.make_act(f.P<float>((size_t)B * H * W * mc), mc, H, W, false);     // conv_in is not an igemm: no fused statistics
-        if (!d) { int r = launch_conv_in(x, L.w32[0], L.f32[0], h.p, B, cfg_.in_channels, H, W, mc, stream); if (r) return r; }
+        // round 6: conv_in emits the GroupNorm statistics of its output itself (the two GroupNorms that read it -- input_blocks.1.0 and, through
+        // the skip concat, the last output block -- ran the statistics kernel; rounds 1-5: "conv_in is not an igemm: no fused statistics")
+        const char* e_cis = getenv("SDMI_CONV_IN_STATS");                 // (A/B knob, read per call; 0 = the statistics kernel as in rounds 1-5)
+        h = f.make_act(f.P<float>((size_t)B * H * W * mc), mc, H, W, (H * W) % 16 == 0 && !(e_cis && atoi(e_cis) == 0));
+        IGemmParams st;                                   // (carrier of the statistics targets only)
+        f.attach_gn_targets(st, h);
+        if (!d) {
+          int r = launch_conv_in(x, L.w32[0], L.f32[0], h.p, B, cfg_.in_channels, H, W, mc, stream, st.gn_n, st.gn_acc, st.gn_cpg, st.gn_cbase);
+          if (r) return r;
+        }
         hs.push_back(h);
       }
       for (size_t bi = 1; bi < input_blocks_.size(); ++bi) {

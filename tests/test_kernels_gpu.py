@@ -725,6 +725,41 @@ def test_attention(d, heads, nq, nkv):
     assert K.report(f'attention d{d} nq{nq} nkv{nkv}', out, ref, 3e-3) < 3e-3
 
 
+@pytest.mark.parametrize('heads,nq,nkv', [(8, 4096, 4096), (2, 2048, 4096), (3, 4096 + 64, 2048 + 128), (1, 9216, 9216)])
+def test_attention_key_split(heads, nq, nkv, monkeypatch):
+    """attn_dma_kernel KVS = 2 (round 6; d = 40 self-attention of the 64 x 64 / 96 x 96 levels): two 8-wave groups of one workgroup take half of the
+    keys each and merge their softmax partials through LDS.  Against fp32 torch like test_attention (same tolerance), against the one-group
+    kernel (the two differ by the fp32 rounding of the merge and by P being rounded relative to each half's running maximum), with outliers in
+    BOTH halves and at the seam so that both rescale paths and the merge weights 2^(m_g - m) run; ragged query counts; bit-identical repeats."""
+    d = 40
+    g = _g(7000 + nq + nkv)
+    BH = heads
+    q = _rand16((BH, nq, d), g)
+    k = _rand16((BH, nkv, d), g)
+    v = _rand16((BH, nkv, d), g)
+    q[0, 0] *= 6.0
+    k[0, nkv - 1] *= 6.0                   # second half
+    k[0, nkv // 2 - 1] *= 5.0              # last key of the first half
+    k[0, 3] *= 7.0                         # first half
+    scale = d ** -0.5
+    ref = torch.cat([torch.bmm((torch.bmm(q[i:i + 1].float(), k[i:i + 1].float().transpose(1, 2)) * scale).softmax(-1), v[i:i + 1].float())
+                     for i in range(BH)]).reshape(1, heads, nq, d).permute(0, 2, 1, 3).reshape(1, nq, heads * d)
+    vt = v.transpose(1, 2).contiguous()
+    qd, kd, vd = q.to(DEV), k.to(DEV), vt.to(DEV)
+    monkeypatch.setenv('SDMI_ATTN_KVS', '0')
+    one = K.attention(qd, kd, vd, heads, nkv, scale).clone()
+    monkeypatch.setenv('SDMI_ATTN_KVS', '2')          # (2 = also above 4096 keys, where the default keeps the 8-wave kernel)
+    two = K.attention(qd, kd, vd, heads, nkv, scale).clone()
+    again = K.attention(qd, kd, vd, heads, nkv, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(two, again)
+    e1 = K.report(f'attention one group  d40 nq{nq} nkv{nkv}', one, ref, 3e-3)
+    e2 = K.report(f'attention key split  d40 nq{nq} nkv{nkv}', two, ref, 3e-3)
+    dd = (one.float() - two.float()).abs().max().item()
+    print(f'[attention key split nq{nq} nkv{nkv}] split vs one group max-abs {dd:.3e}', flush=True)
+    assert e2 < 3e-3 and e2 <= 1.5 * e1 + 2e-4 and dd < 3e-3
+
+
 @pytest.mark.parametrize('d,heads,n', [(64, 12, 77), (64, 2, 40), (32, 4, 130)])
 def test_attention_causal(d, heads, n):
     """CLIPTextModel self-attention: softmax over keys <= query (transformers modeling_clip.py, causal mask)."""
