@@ -109,6 +109,29 @@ def test_unet_eps_matches_reference_golden(case, golden_dir):
     assert float(err.pow(2).mean().sqrt()) <= bar_rms
 
 
+@pytest.mark.parametrize('case', ['sdv1_real_16x16', 'sdv1_real1_16x16', 'sdv1_real_64x64'])
+def test_outlier_family_stays_inside_the_fp16_range(case, golden_dir):
+    """the outlier goldens through the fp16 range guard (SDMI_CHECK_RANGE / debug.range_check: every fp16 MFMA operand is
+    scanned right after the launch that wrote it).  Context channels at |x| ~ 30, x8 gammas and x8 weight rows must not push any operand past
+    6e4 or produce a non-finite value; the guarded call goes through the executor (no launch tape) and must give the bits of the unguarded one."""
+    from stable_diffusion_amd import debug
+    z = np.load(os.path.join(golden_dir, f'unet_{case}.npz'))
+    cfg = CFGS[case.split('_')[0]]
+    m, sd = _model(case.split('_')[0], int(z['weight_seed']), _style(z))
+    x, t, ctx = make_inputs(cfg, int(z['batch']), int(z['h']), int(z['w']), seed=int(z['input_seed']),
+                            ctx_len=int(z['ctx_len']), timesteps=tuple(int(v) for v in z['t']), style=_style(z))
+    plain = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+    debug.range_check(True)
+    try:
+        guarded = m(x.cuda(), t.cuda(), context=ctx.cuda()).clone()
+        rep = debug.range_report()
+    finally:
+        debug.range_check(False)
+    print(f'[range {case}] largest fp16 operand {rep["max_abs"]:.1f}, over 6e4: {rep["over_6e4"]}, non-finite: {rep["nonfinite"]}', flush=True)
+    assert rep['over_6e4'] == 0 and rep['nonfinite'] == 0 and rep['max_abs'] < 6.0e4
+    assert torch.equal(plain, guarded)
+
+
 def test_parity_headroom_report():
     """The margin to the bar is thin by construction (rms 1.6e-4 with a 5-6 sigma tail); print it per case so that a change
     of tile / split-K choices that erodes it is visible in the log before it fails."""
