@@ -751,8 +751,13 @@ def test_attention_key_split(heads, nq, nkv, monkeypatch):
     monkeypatch.setenv('SDMI_ATTN_KVS', '2')          # (2 = also above 4096 keys, where the default keeps the 8-wave kernel)
     two = K.attention(qd, kd, vd, heads, nkv, scale).clone()
     again = K.attention(qd, kd, vd, heads, nkv, scale)
+    monkeypatch.setenv('SDMI_ATTN_ROT', '1')          # the second key group runs its tile blocks rotated: the same values, the same bits
+    rot = K.attention(qd, kd, vd, heads, nkv, scale).clone()
+    monkeypatch.setenv('SDMI_ATTN_ROT', '0')
+    unrot = K.attention(qd, kd, vd, heads, nkv, scale)
     torch.cuda.synchronize()
     assert torch.equal(two, again)
+    assert torch.equal(rot, unrot), float((rot.float() - unrot.float()).abs().max())
     e1 = K.report(f'attention one group  d40 nq{nq} nkv{nkv}', one, ref, 3e-3)
     e2 = K.report(f'attention key split  d40 nq{nq} nkv{nkv}', two, ref, 3e-3)
     dd = (one.float() - two.float()).abs().max().item()
