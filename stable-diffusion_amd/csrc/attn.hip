@@ -301,7 +301,10 @@ __device__ __forceinline__ float sum_across_halves(float x) {
 // Q K^T(t), softmax(t), P V(t): the four waves of a SIMD no longer all want the VALU (the softmax: 60 % of a tile) in the same phase.  One barrier
 // per tile as before; group 1 needs tile t + 1 landed one interval earlier (one LDS-DMA tile less in flight for that group).  Same values, same
 // per-wave arithmetic: bit-identical to the unrotated key split.
-template <int D, int NW, int NS, bool CAUSAL, int ABL = 0, int KVS = 1, bool ROT = false>
+// TPB = 2 (round 6): ONE barrier per TWO key tiles.  The ring of four stages holds the pair being read and the pair in flight; the waves of a
+// group may drift up to two tiles apart, so the four waves of a SIMD stop marching through matrix and VALU phases in lock-step.  Same values, same
+// per-wave arithmetic, same bits.
+template <int D, int NW, int NS, bool CAUSAL, int ABL = 0, int KVS = 1, bool ROT = false, int TPB = 1>
 __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
   constexpr int DKS = (D + 15) / 16;   // k-steps of 16 over the head dim (QK^T)
@@ -319,6 +322,7 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   constexpr int NWQ = NW / KVS;                                    // query waves (waves per key group)
   static_assert(KVS == 1 || (KVS == 2 && !CAUSAL && NW % 2 == 0), "key split: two groups, no causal mask");
   static_assert(!ROT || (KVS == 2 && NS >= 4 && ABL == 0), "rotated key group: needs the key split and a ring of four stages");
+  static_assert(TPB == 1 || (TPB == 2 && NS == 4 && !ROT && ABL == 0), "two tiles per barrier: a ring of exactly four stages");
   constexpr int PPW = (PT + NWQ - 1) / NWQ;                        // per wave (the surplus re-issues the last piece)
   static_assert(NS >= 2 && KVS * NS * STAGE <= 160 * 1024, "LDS budget");
   static_assert(KVS == 1 || NWQ * (DVT * 16 + 2) * 64 * 4 <= KVS * NS * STAGE, "the hand-over of the key groups lives in the (drained) rings");
@@ -410,9 +414,10 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
     for (int j = 0; j < PPW; ++j) pv_off[j] += t_first * pv_step[j];       // (the out-of-range marker has a zero step)
   }
 #pragma unroll
-  for (int s2 = 0; s2 < NS - 1; ++s2) issue_tile(s2);          // (tiles past nt read out of range: zeros, never consumed)
+  for (int s2 = 0; s2 < (TPB == 2 ? 2 : NS - 1); ++s2) issue_tile(s2);          // (tiles past nt read out of range: zeros, never consumed)
   const bool rot = ROT && grp == 1;                           // (wave-uniform)
-  if (rot) wait_dma<PPW*(NS - 3 > 0 ? NS - 3 : 0)>(); else wait_dma<PPW*(NS - 2)>();
+  if (TPB == 2) wait_dma<0>();
+  else if (rot) wait_dma<PPW*(NS - 3 > 0 ? NS - 3 : 0)>(); else wait_dma<PPW*(NS - 2)>();
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   const int ksw = (l31 >> 1) & 7;
   int cur = 0, nxt = NS - 1;
@@ -420,16 +425,21 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   // S^T = K Q^T of the tile in ring stage `stage` (two 32-key blocks)
   auto qk_tile = [&](int stage) {
     const unsigned char* Kq = smem + (ABL == 6 ? 0 : stage) * STAGE;
+    // (round 6: the first k-step takes the constant 0 as its C operand -- an inline constant of the MFMA -- instead of 32 v_mov_b32 per tile that
+    // zeroed the score accumulators: 18 % of the loop's VALU issue at d = 40; the same sums, the same bits)
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kvb = 0; kvb < KVT / 32; ++kvb) {
+      if (ABL == 5) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) s[kvb][r] = 0.f;
+        for (int r = 0; r < 16; ++r) s[kvb][r] = 0.f;
+      }
 #pragma unroll
       for (int ks = 0; ks < DKS; ++ks) {
         const unsigned char* kp = Kq + ((ks >> 2) * 64 + kvb * 32 + l31) * 128 + ((((ks & 3) * 2 + lg) ^ ksw) << 4);
         const f16x8 a = *(const f16x8*)kp;
         if (ABL == 5) { s[kvb][ks] += (float)a[0]; continue; }
-        s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], s[kvb], 0, 0, 0);
+        s[kvb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, qf[ks], ks == 0 ? zero16 : s[kvb], 0, 0, 0);
       }
     }
   };
@@ -438,7 +448,9 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
   // arbitration (MI355X_MICROARCH.md "two waves per SIMD", item 4).  One static s_setprio for that half, no per-phase flips.
   if (NW == 8 && p.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
   for (int t = 0; t < nt; ++t) {
-    if (ABL != 2) issue_tile(nxt);
+    if (TPB == 2) {
+      if ((t & 1) == 0) { issue_tile((cur + 2) & 3); issue_tile((cur + 3) & 3); }     // the next pair, into the stages of the pair before this one
+    } else if (ABL != 2) issue_tile(nxt);
     const unsigned char* Ks = smem + (ABL == 6 ? 0 : cur) * STAGE;
     const unsigned char* Vs = Ks + KROWS * 128;
 
@@ -506,7 +518,12 @@ __global__ void __launch_bounds__(NW * 64) attn_dma_kernel(const AttnParams p) {
       }
     }
     if (rot && t + 1 < nt) qk_tile((cur + 1 == NS) ? 0 : cur + 1);      // the rotated group: next tile's scores behind this tile's P V
-    if (ABL != 1) {
+    if (TPB == 2) {
+      if ((t & 1) || t + 1 == nt) {                        // behind the second tile of a pair (or a lone last tile)
+        wait_dma<0>();                                     // the next pair has landed
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+    } else if (ABL != 1) {
       if (rot) wait_dma<PPW*(NS - 3 > 0 ? NS - 3 : 0)>();  // (rotated group: tile t + 2 has to be there for the next interval's Q K^T)
       else wait_dma<PPW*(NS - 2)>();                       // this wave's pieces of tile t + 1 have landed
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   // ... everybody's; and tile t is fully read
@@ -829,6 +846,9 @@ __global__ void __launch_bounds__(512) attn_pp_kernel(const AttnParams p) {
 #define SDMI_EXP_ENV(name, def) (def)
 #endif
 
+#ifndef SDMI_ATTN_TPB_DEFAULT
+#define SDMI_ATTN_TPB_DEFAULT 1
+#endif
 #ifndef SDMI_ATTN_ROT_DEFAULT
 #define SDMI_ATTN_ROT_DEFAULT 0
 #endif
@@ -860,8 +880,10 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
   // per launch at 4096 keys, UNet call -0.019 ms at 64 x 64 but +0.06 ms at 96 x 96 (9216 keys: the 8-wave kernel stays there).
   // SDMI_ATTN_KVS=0 restores the 8-wave kernel everywhere, =2 forces the split for every even tile count >= 32 (A/B; read per launch)
   const int kvs_env = getenv("SDMI_ATTN_KVS") ? atoi(getenv("SDMI_ATTN_KVS")) : SDMI_ATTN_KVS_DEFAULT;
-  const char* e_rot = getenv("SDMI_ATTN_ROT");                 // (A/B, read per launch) the second key group runs its tile blocks rotated
-  const bool kvs_rot = e_rot ? atoi(e_rot) != 0 : (SDMI_ATTN_ROT_DEFAULT != 0);
+  // (experiments build, read per launch) one barrier per two key tiles / the second key group's tile blocks rotated
+  const bool tpb2 = SDMI_EXP_ENV("SDMI_ATTN_TPB", SDMI_ATTN_TPB_DEFAULT) == 2;
+  const bool kvs_rot = SDMI_EXP_ENV("SDMI_ATTN_ROT", SDMI_ATTN_ROT_DEFAULT) != 0;
+  (void)tpb2; (void)kvs_rot;
   const bool kvs2 = D == 40 && nw == 8 && !p.causal && !p.pingpong && p.nkv % (2 * KVT) == 0 && p.nkv >= 32 * KVT && kvs_env != 0 && (p.nkv <= 64 * KVT || kvs_env == 2);
   if (!use_v1 && !p.causal && (p.nkv * D) % 8 == 0) {
     // timing-only ablations (WRONG results: each removes one ingredient of the loop, tools/attn_ablate.py) exist only in a build with
@@ -891,9 +913,17 @@ int launch_d(const AttnParams& p, hipStream_t stream) {
 #endif
     } else if (nw == 8 && kvs2) {
       if constexpr (D == 40) {
+#ifdef SDMI_EXPERIMENTS      // (both bit-identical to the plain key split and measured slower: profiles/attn_kvsplit_r06.txt)
         if (kvs_rot) SDMI_LAUNCH((attn_dma_kernel<D, 16, DNS, false, 0, 2, true>), grid, dim3(1024), 0, stream, p);
-        else SDMI_LAUNCH((attn_dma_kernel<D, 16, DNS, false, 0, 2>), grid, dim3(1024), 0, stream, p);
+        else if (tpb2) SDMI_LAUNCH((attn_dma_kernel<D, 16, DNS, false, 0, 2, false, 2>), grid, dim3(1024), 0, stream, p);
+        else
+#endif
+        SDMI_LAUNCH((attn_dma_kernel<D, 16, DNS, false, 0, 2>), grid, dim3(1024), 0, stream, p);
       }
+#ifdef SDMI_EXPERIMENTS
+    } else if (nw == 8 && tpb2 && D == 40) {
+      if constexpr (D == 40) SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false, 0, 1, false, 2>), grid, dim3(512), 0, stream, p);
+#endif
     } else if (nw == 8) SDMI_LAUNCH((attn_dma_kernel<D, 8, DNS, false>), grid, dim3(512), 0, stream, p);
     else if (nw == 4) SDMI_LAUNCH((attn_dma_kernel<D, 4, DNS, false>), grid, dim3(256), 0, stream, p);
     else SDMI_LAUNCH((attn_dma_kernel<D, 2, DNS, false>), grid, dim3(128), 0, stream, p);

@@ -751,13 +751,20 @@ def test_attention_key_split(heads, nq, nkv, monkeypatch):
     monkeypatch.setenv('SDMI_ATTN_KVS', '2')          # (2 = also above 4096 keys, where the default keeps the 8-wave kernel)
     two = K.attention(qd, kd, vd, heads, nkv, scale).clone()
     again = K.attention(qd, kd, vd, heads, nkv, scale)
-    monkeypatch.setenv('SDMI_ATTN_ROT', '1')          # the second key group runs its tile blocks rotated: the same values, the same bits
-    rot = K.attention(qd, kd, vd, heads, nkv, scale).clone()
-    monkeypatch.setenv('SDMI_ATTN_ROT', '0')
-    unrot = K.attention(qd, kd, vd, heads, nkv, scale)
     torch.cuda.synchronize()
     assert torch.equal(two, again)
-    assert torch.equal(rot, unrot), float((rot.float() - unrot.float()).abs().max())
+    from stable_diffusion_amd import _lib
+    if _lib.load().sdmi_has_experiments():
+        # experiments build: the rotated second key group and one barrier per two key tiles -- the same values, the same bits (both measured slower)
+        monkeypatch.setenv('SDMI_ATTN_ROT', '1')
+        rot = K.attention(qd, kd, vd, heads, nkv, scale).clone()
+        monkeypatch.setenv('SDMI_ATTN_ROT', '0')
+        monkeypatch.setenv('SDMI_ATTN_TPB', '2')
+        tp = K.attention(qd, kd, vd, heads, nkv, scale).clone()
+        monkeypatch.setenv('SDMI_ATTN_KVS', '0')
+        tp8 = K.attention(qd, kd, vd, heads, nkv, scale).clone()
+        torch.cuda.synchronize()
+        assert torch.equal(rot, two) and torch.equal(tp, two) and torch.equal(tp8, one)
     e1 = K.report(f'attention one group  d40 nq{nq} nkv{nkv}', one, ref, 3e-3)
     e2 = K.report(f'attention key split  d40 nq{nq} nkv{nkv}', two, ref, 3e-3)
     dd = (one.float() - two.float()).abs().max().item()
